@@ -1,0 +1,174 @@
+/* jpegblk.h -- C ABI of the MI355X-native JPEG block pipeline
+ *             (dequantize -> 8x8 inverse DCT -> YCbCr->RGB).
+ *
+ * This library replaces ONE seam of the reference decoder (aswanthabam/JPEG_Decoder): the
+ * three consecutive calls
+ *
+ *     this->mcus = decodeHuffman();
+ *     dequantize();  inverseDCT();  YCbCrToRGB();        reference jpeg.cpp:785-788
+ *
+ * inside Image::process_image_data (jpeg.cpp:755-789).  Everything before the seam (marker
+ * parsing, Huffman decoding) runs on the host; everything behind this ABI runs as
+ * hand-written HIP kernels on gfx950.  There is no CPU fallback in this library: if no HIP
+ * device is usable every compute entry point returns JB_ERR_HIP.
+ *
+ * DATA CONTRACT (what the seam carries)
+ *   coefficients  int16, natural (de-zigzagged) order, 64 per 8x8 block (128 B), blocks in
+ *                 decode order = the order decodeHuffman() visits them (jpeg.cpp:415-443):
+ *                 MCUs in raster order; per MCU hs*vs luma blocks (v-major, h-minor), then
+ *                 one Cb block, then one Cr block.  The reference stores them as
+ *                 MCU::y/cb/cr int[64] (include/types.hpp:32-67).
+ *   quant tables  up to 4 tables x 64 entries, natural order, uint16.  (The reference keeps
+ *                 one byte per entry -- jpeg.cpp:216,223, types.hpp:86-92 -- so parity with it
+ *                 is defined for entries <= 255.)
+ *   geometry      jb_image_desc; derived sizes as read_sof computes them (jpeg.cpp:77-80,
+ *                 118-127) are returned by jb_geometry().
+ *   pixels        uint8 R,G,B interleaved, row stride given in bytes, cropped to
+ *                 width x height: rgb[y*stride + 3*x + c] =
+ *                 mcus[(y/8)*mcuWidthReal + x/8].{r,g,b}[(y%8)*8 + x%8], the linearisation
+ *                 both reference sinks use (include/display.hpp:19-34, jpeg.cpp:488-499).
+ *
+ * ARITHMETIC CONTRACT: bit-exact with the reference CPU path (int32 dequantize, the float AAN
+ * butterfly network of jpeg.cpp:594-732 with truncation toward zero after each 1-D pass, the
+ * float colour transform of jpeg.cpp:521-535 with truncation then clamp) for every int16
+ * coefficient and every table entry <= 255.
+ *
+ * OWNERSHIP: all buffers are caller-owned; the library never frees or retains caller pointers
+ * past the call (async: past jb_wait).  ERRORS: every function returns a jb_status, never
+ * calls exit() (the reference logs and exit(1)s, e.g. jpeg.cpp:71-72,85-86).
+ * THREADING: a jb_ctx is bound to one device and one HIP stream; calls on one ctx must be
+ * serialised by the caller, different contexts may be used concurrently from different threads.
+ */
+#ifndef JPEGBLK_H
+#define JPEGBLK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JB_ABI_VERSION 1
+
+typedef enum jb_status {
+  JB_OK = 0,
+  JB_ERR_NULL = -1,        /* a required pointer is NULL                                   */
+  JB_ERR_GEOMETRY = -2,    /* width/height/stride out of range                             */
+  JB_ERR_SAMPLING = -3,    /* luma factors not in {1,2}x{1,2} (reference jpeg.cpp:110-136) */
+  JB_ERR_QTAB = -4,        /* qtab_id outside 0..3 (reference jpeg.cpp:205-209)            */
+  JB_ERR_CAPACITY = -5,    /* image larger than the context / buffer was created for       */
+  JB_ERR_HIP = -6,         /* HIP runtime error; text via jb_last_error()                  */
+  JB_ERR_STATE = -7,       /* bad ticket / nothing in flight / context busy                */
+  JB_ERR_FORMAT = -8,      /* front end: not a JPEG / corrupt segment                      */
+  JB_ERR_UNSUPPORTED = -9  /* front end: progressive, !=3 components, ... (jpeg.cpp:69-87) */
+} jb_status;
+
+/* What Image state the seam reads: image_width/height (jpeg.cpp:792-793), the luma sampling
+ * factors (jpeg.cpp:32-33) and color_components[i].quantizationTableID (jpeg.cpp:23). */
+typedef struct jb_image_desc {
+  int32_t width;      /* pixels, 1..65535 */
+  int32_t height;     /* pixels, 1..65535 */
+  int32_t hs;         /* luma horizontal sampling factor, 1 or 2; chroma is always 1x1 */
+  int32_t vs;         /* luma vertical sampling factor, 1 or 2 */
+  int32_t qtab_id[3]; /* quantisation table of Y, Cb, Cr: 0..3 */
+  int32_t reserved;   /* must be 0 */
+} jb_image_desc;
+
+/* Sizes derived from a descriptor (read_sof, jpeg.cpp:77-80 and 118-127). */
+typedef struct jb_geometry {
+  int32_t mcu_w, mcu_h;           /* 8x8 block columns/rows covering the image: (W+7)/8, (H+7)/8 */
+  int32_t mcu_w_real, mcu_h_real; /* rounded up to a multiple of hs / vs                         */
+  int32_t mcus_x, mcus_y;         /* coded MCUs per row / column                                 */
+  int32_t blocks_per_mcu;         /* hs*vs + 2                                                   */
+  int32_t reserved;
+  int64_t n_coded_blocks;         /* mcus_x*mcus_y*blocks_per_mcu                                */
+  int64_t coef_bytes;             /* n_coded_blocks * 128                                        */
+  int64_t rgb_bytes;              /* width*height*3 (tight rows)                                 */
+} jb_geometry;
+
+typedef struct jb_ctx jb_ctx;
+
+/* ---- library / context --------------------------------------------------------------- */
+int jb_abi_version(void);
+/* Number of HIP devices visible, or a negative jb_status. */
+int jb_device_count(void);
+/* Validate a descriptor and derive its sizes.  Pure host code, no device needed. */
+int jb_geometry_of(const jb_image_desc *desc, jb_geometry *out);
+/* Create a context on `device_id` with its own stream.  `max_coef_bytes`/`max_rgb_bytes`
+ * size the per-slot device and pinned staging buffers used by the host-buffer entry points
+ * (0,0: device-pointer entry points only).  `n_slots` (1..8) = depth of the staging ring. */
+int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, int n_slots,
+                  jb_ctx **out);
+void jb_ctx_destroy(jb_ctx *ctx);
+/* Text of the last error on this context (or of the last context-less error on this thread
+ * when ctx is NULL).  Never NULL. */
+const char *jb_last_error(const jb_ctx *ctx);
+/* The context's HIP stream (hipStream_t) so callers can order their own work against it. */
+void *jb_ctx_stream(jb_ctx *ctx);
+/* Block until everything submitted to the context's stream has finished. */
+int jb_ctx_synchronize(jb_ctx *ctx);
+
+/* ---- the seam: host buffers (drop-in for jpeg.cpp:786-788) ----------------------------- */
+/* Synchronous: copies coefficients to the device, runs the fused kernel, copies pixels back.
+ * `qtabs` = 4*64 uint16 natural order (tables not referenced by desc->qtab_id may be 0). */
+int jb_blocks_to_rgb(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef,
+                     const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride);
+/* Asynchronous flavour over the staging ring, so the host Huffman stage of image i+1 overlaps
+ * the device work of image i.  `coef`/`rgb` should come from jb_pinned_alloc for true overlap
+ * and must stay valid until jb_wait(ticket) returns.  Blocks only when all slots are busy. */
+int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef,
+              const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride, int *ticket);
+int jb_wait(jb_ctx *ctx, int ticket);
+void *jb_pinned_alloc(size_t bytes);
+void jb_pinned_free(void *p);
+
+/* ---- the seam: device-resident buffers (what bench.py and multi-image batches use) ------ */
+/* A batch = n_images images of identical geometry, processed by ONE kernel launch on `stream`
+ * (NULL = the context's stream).  Every pointer is a device pointer.  d_qtabs holds, per image
+ * (or once, when qtab_image_stride == 0), three tables int32[3][64] already resolved per
+ * component (Y, Cb, Cr) in natural order; build them with jb_resolve_qtabs(). */
+typedef struct jb_device_batch {
+  jb_image_desc desc;
+  int32_t n_images;
+  int32_t reserved;
+  const int16_t *d_coef;
+  int64_t coef_image_stride; /* bytes between images, multiple of 16 */
+  const int32_t *d_qtabs;
+  int64_t qtab_image_stride; /* bytes between images' [3][64] tables; 0 = shared */
+  uint8_t *d_rgb;
+  int64_t rgb_image_stride; /* bytes between images */
+  int64_t rgb_row_stride;   /* bytes between pixel rows, >= 3*width */
+} jb_device_batch;
+
+int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *batch, void *stream);
+/* Host helper: expand (qtabs uint16[4][64], qtab_id[3]) into the int32[3][64] the kernel reads. */
+int jb_resolve_qtabs(const jb_image_desc *desc, const uint16_t *qtabs, int32_t *out192);
+/* Name of the kernel jb_blocks_to_rgb_device launches for this descriptor (for profilers). */
+const char *jb_kernel_name(const jb_image_desc *desc);
+
+/* ---- host front end ("next" rows of the scope table; reference jpeg.cpp:67-446, 826-907,
+ *      include/file.hpp, include/huffman.hpp) --------------------------------------------- */
+/* Parse a baseline JFIF byte stream and Huffman-decode its scan into packed int16 blocks in
+ * the order described above.  Two-call protocol: with coef == NULL only the headers are parsed
+ * and *desc / qtabs are filled (size the buffer with jb_geometry_of); with coef != NULL
+ * (capacity coef_cap_bytes) the scan is decoded too.  Rejects what the reference rejects
+ * (progressive SOF2, != 3 components, chroma not 1x1, luma factors outside {1,2}). */
+int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
+                      uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes);
+/* decode(path) -> RGB: the reference's whole `Image(path); readJPEG();` surface
+ * (jpeg.cpp:797-807, 826-907) minus the X11 sink.  *rgb is malloc'd (tight rows, width*3);
+ * release it with jb_free(). */
+int jb_decode_file(jb_ctx *ctx, const char *path, uint8_t **rgb, int32_t *width, int32_t *height);
+int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t **rgb,
+                     int32_t *width, int32_t *height);
+void jb_free(void *p);
+/* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
+ * jpeg.cpp:462-509): binary PPM (P6). */
+int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,
+                 int64_t rgb_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGBLK_H */

@@ -1,0 +1,98 @@
+"""CPU tests: pin the oracle (oracle/jpegblk_oracle.c) to the reference.
+
+(1) against the committed golden vectors generated from the genuine reference build
+    (oracle/gen_golden.py) -- runs everywhere;
+(2) directly against oracle/_ref/libjpegref.so (the reference compiled in place) when that
+    build is present.
+Parity bar: bit-exact (the task's +-1 LSB allowance is not used)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import BASELINE_IMAGES, load_golden, load_kat
+from jpeg_decoder_amd import synth
+from oracle.pyoracle import Ref, make_desc
+
+# f32 bit patterns of reference include/types.hpp:5-19 and jpeg.cpp:521-523
+EXPECTED_CONSTANTS = [0x3FEC835E, 0x3FB504F3, 0x3F8A8BD4, 0x3FB504F3, 0x40273D74, 0x3F43EF15,
+                      0x3EB504F3, 0x3EFB14BE, 0x3EEC835E, 0x3ED4DB31, 0x3EB504F3, 0x3E8E39DA,
+                      0x3E43EF15, 0x3DC7C5C2, 0x3FB374BC, 0x3EB020C5, 0x3F36C8B4, 0x3FE2D0E5]
+
+
+def test_constants_match_reference(oracle, manifest):
+    assert [int(x) for x in oracle.constants()] == EXPECTED_CONSTANTS
+    assert manifest["constants_f32_bits"] == EXPECTED_CONSTANTS
+
+
+@pytest.mark.parametrize("name", BASELINE_IMAGES)
+def test_oracle_matches_golden_image(oracle, manifest, name):
+    desc, coef, qtabs, rgb = load_golden(name)
+    out = oracle.blocks_to_rgb(desc, coef, qtabs)
+    assert out.shape == rgb.shape
+    assert np.array_equal(out, rgb)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == manifest["images"][name]["rgb_sha256"]
+    g = oracle.geometry(desc)
+    m = manifest["images"][name]
+    assert (g.mcu_w_real, g.mcu_h_real, g.n_coded_blocks) == (m["mcu_w_real"], m["mcu_h_real"], m["n_coded_blocks"])
+
+
+def test_oracle_matches_golden_kat(oracle, manifest):
+    kat = load_kat()
+    assert len(kat) == len(manifest["kat"]) >= 50
+    for name, (desc, coef, qtabs, rgb) in kat.items():
+        out = oracle.blocks_to_rgb(desc, coef, qtabs)
+        assert np.array_equal(out, rgb), name
+
+
+def test_oracle_threads_agree(oracle):
+    desc, coef, qtabs, rgb = load_golden("img")
+    assert np.array_equal(oracle.blocks_to_rgb(desc, coef, qtabs, nthreads=3), rgb)
+
+
+def test_oracle_row_stride(oracle):
+    desc, coef, qtabs, rgb = load_golden("img2")
+    out = oracle.blocks_to_rgb(desc, coef, qtabs, stride=3 * desc.width + 13)
+    assert np.array_equal(out, rgb)
+
+
+def test_oracle_rejects_bad_descriptors(oracle):
+    from oracle.pyoracle import Geometry
+    import ctypes
+    for bad, rc in [(make_desc(0, 8, 1, 1), -2), (make_desc(8, 70000, 1, 1), -2),
+                    (make_desc(8, 8, 3, 1), -3), (make_desc(8, 8, 1, 4), -3),
+                    (make_desc(8, 8, 1, 1, (0, 4, 1)), -4)]:
+        g = Geometry()
+        assert oracle.lib.jbo_geometry_of(ctypes.byref(bad), ctypes.byref(g)) == rc
+
+
+def test_dc_only_block_is_flat(oracle):
+    # DC-only block: every 1-D pass sees one non-zero input -> a flat block.  800*s0 = 282.84
+    # truncates to 282 after the column pass, 282*s0 = 99.70 truncates to 99 after the row
+    # pass (an exact IDCT with rounding would give 100): the reference's two truncations.
+    blk = np.zeros(64, np.int32)
+    blk[0] = 800
+    out = oracle.idct_block(blk)
+    assert (out == out[0]).all() and out[0] == 99
+
+
+needs_ref = pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not built (reference absent)")
+
+
+@needs_ref
+def test_ref_constants(oracle):
+    assert np.array_equal(Ref().constants(), oracle.constants())
+
+
+@needs_ref
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_oracle_matches_reference_on_random_blocks(oracle, hs, vs):
+    ref = Ref()
+    q = synth.annex_k_qtabs(75)
+    q[2] = 255
+    q[3] = 1
+    for (w, h, seed) in [(8, 8, 1), (100, 52, 2), (257, 131, 3)]:
+        d = make_desc(w, h, hs, vs, (0, 1, 2))
+        n = oracle.geometry(d).n_coded_blocks
+        for coef in (synth.random_blocks(n, seed), synth.random_blocks(n, seed + 10, -64, 64)):
+            assert np.array_equal(oracle.blocks_to_rgb(d, coef, q), ref.blocks_to_rgb(d, coef, q))
