@@ -1,0 +1,236 @@
+"""ctypes binding of include/jpegblk.h (libjpegblk.so).  One Python function per C entry point;
+no arithmetic happens on this side."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjpegblk.so")
+
+JB_OK = 0
+STATUS_NAMES = {0: "JB_OK", -1: "JB_ERR_NULL", -2: "JB_ERR_GEOMETRY", -3: "JB_ERR_SAMPLING",
+                -4: "JB_ERR_QTAB", -5: "JB_ERR_CAPACITY", -6: "JB_ERR_HIP", -7: "JB_ERR_STATE",
+                -8: "JB_ERR_FORMAT", -9: "JB_ERR_UNSUPPORTED"}
+
+
+class JbError(RuntimeError):
+    def __init__(self, status, text=""):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {text}")
+
+
+class ImageDesc(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("hs", ctypes.c_int32), ("vs", ctypes.c_int32),
+                ("qtab_id", ctypes.c_int32 * 3), ("reserved", ctypes.c_int32)]
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [("mcu_w", ctypes.c_int32), ("mcu_h", ctypes.c_int32),
+                ("mcu_w_real", ctypes.c_int32), ("mcu_h_real", ctypes.c_int32),
+                ("mcus_x", ctypes.c_int32), ("mcus_y", ctypes.c_int32),
+                ("blocks_per_mcu", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_coded_blocks", ctypes.c_int64), ("coef_bytes", ctypes.c_int64),
+                ("rgb_bytes", ctypes.c_int64)]
+
+
+class DeviceBatch(ctypes.Structure):
+    _fields_ = [("desc", ImageDesc), ("n_images", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("d_coef", ctypes.c_void_p), ("coef_image_stride", ctypes.c_int64),
+                ("d_qtabs", ctypes.c_void_p), ("qtab_image_stride", ctypes.c_int64),
+                ("d_rgb", ctypes.c_void_p), ("rgb_image_stride", ctypes.c_int64),
+                ("rgb_row_stride", ctypes.c_int64)]
+
+
+def build_library():
+    """Compile csrc/ for gfx950 into jpeg_decoder_amd/libjpegblk.so (hipcc cross-compiles
+    without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the block pipeline)")
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    pd = ctypes.POINTER(ImageDesc)
+    L.jb_abi_version.restype = ctypes.c_int
+    L.jb_device_count.restype = ctypes.c_int
+    L.jb_geometry_of.argtypes = [pd, ctypes.POINTER(Geometry)]
+    L.jb_ctx_create.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    L.jb_ctx_destroy.argtypes = [vp]
+    L.jb_ctx_destroy.restype = None
+    L.jb_last_error.argtypes = [vp]
+    L.jb_last_error.restype = ctypes.c_char_p
+    L.jb_ctx_stream.argtypes = [vp]
+    L.jb_ctx_stream.restype = vp
+    L.jb_ctx_synchronize.argtypes = [vp]
+    L.jb_blocks_to_rgb.argtypes = [vp, pd, vp, vp, vp, i64]
+    L.jb_submit.argtypes = [vp, pd, vp, vp, vp, i64, ctypes.POINTER(ctypes.c_int)]
+    L.jb_wait.argtypes = [vp, ctypes.c_int]
+    L.jb_pinned_alloc.argtypes = [ctypes.c_size_t]
+    L.jb_pinned_alloc.restype = vp
+    L.jb_pinned_free.argtypes = [vp]
+    L.jb_pinned_free.restype = None
+    L.jb_blocks_to_rgb_device.argtypes = [vp, ctypes.POINTER(DeviceBatch), vp]
+    L.jb_resolve_qtabs.argtypes = [pd, vp, vp]
+    L.jb_kernel_name.argtypes = [pd]
+    L.jb_kernel_name.restype = ctypes.c_char_p
+    L.jb_entropy_decode.argtypes = [vp, ctypes.c_size_t, pd, vp, vp, ctypes.c_size_t]
+    L.jb_decode_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.jb_decode_memory.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.jb_free.argtypes = [vp]
+    L.jb_free.restype = None
+    L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
+    if L.jb_abi_version() != 1:
+        raise ImportError("libjpegblk.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def make_desc(width, height, hs, vs, qtab_id=(0, 1, 1)):
+    d = ImageDesc()
+    d.width, d.height, d.hs, d.vs = int(width), int(height), int(hs), int(vs)
+    for i in range(3):
+        d.qtab_id[i] = int(qtab_id[i])
+    d.reserved = 0
+    return d
+
+
+def _check(rc, ctx=None):
+    if rc != JB_OK:
+        raise JbError(rc, lib().jb_last_error(ctx).decode(errors="replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def geometry_of(desc):
+    g = Geometry()
+    _check(lib().jb_geometry_of(ctypes.byref(desc), ctypes.byref(g)))
+    return g
+
+
+def resolve_qtabs(desc, qtabs):
+    """(uint16 [4,64], desc.qtab_id) -> int32 [3,64], the layout the kernel reads."""
+    q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(4, 64)
+    out = np.zeros((3, 64), np.int32)
+    _check(lib().jb_resolve_qtabs(ctypes.byref(desc), _ptr(q), _ptr(out)))
+    return out
+
+
+def entropy_decode(jpeg_bytes, headers_only=False):
+    """Host front end: JFIF bytes -> (desc, qtabs uint16 [4,64], coef int16 [n,64] or None)."""
+    buf = np.frombuffer(jpeg_bytes, dtype=np.uint8)
+    desc = ImageDesc()
+    q = np.zeros((4, 64), np.uint16)
+    _check(lib().jb_entropy_decode(_ptr(buf), buf.size, ctypes.byref(desc), _ptr(q), None, 0))
+    if headers_only:
+        return desc, q, None
+    g = geometry_of(desc)
+    coef = np.zeros((g.n_coded_blocks, 64), np.int16)
+    _check(lib().jb_entropy_decode(_ptr(buf), buf.size, ctypes.byref(desc), _ptr(q), _ptr(coef), coef.nbytes))
+    return desc, q, coef
+
+
+class Context:
+    """jb_ctx: one device, one stream, a ring of staging slots."""
+
+    def __init__(self, device=0, max_coef_bytes=0, max_rgb_bytes=0, n_slots=2):
+        self._h = ctypes.c_void_p()
+        _check(lib().jb_ctx_create(device, max_coef_bytes, max_rgb_bytes, n_slots, ctypes.byref(self._h)))
+
+    @classmethod
+    def for_image(cls, desc, device=0, n_slots=2):
+        g = geometry_of(desc)
+        return cls(device, g.coef_bytes, g.rgb_bytes, n_slots)
+
+    def close(self):
+        if self._h:
+            lib().jb_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().jb_ctx_stream(self._h)
+
+    def synchronize(self):
+        _check(lib().jb_ctx_synchronize(self._h), self._h)
+
+    # -- the seam, host buffers --------------------------------------------------------------
+    def blocks_to_rgb(self, desc, coef, qtabs, stride=None):
+        coef = np.ascontiguousarray(coef, dtype=np.int16)
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(4, 64)
+        stride = stride or 3 * desc.width
+        out = np.zeros((desc.height, stride), np.uint8)
+        _check(lib().jb_blocks_to_rgb(self._h, ctypes.byref(desc), _ptr(coef), _ptr(q), _ptr(out), stride), self._h)
+        return out[:, :3 * desc.width].reshape(desc.height, desc.width, 3)
+
+    def submit(self, desc, coef, qtabs, out, stride=None):
+        """coef / out: numpy arrays that stay alive until wait(ticket)."""
+        q = np.ascontiguousarray(qtabs, dtype=np.uint16).reshape(4, 64)
+        t = ctypes.c_int(-1)
+        _check(lib().jb_submit(self._h, ctypes.byref(desc), _ptr(coef), _ptr(q), _ptr(out),
+                               stride or 3 * desc.width, ctypes.byref(t)), self._h)
+        return t.value
+
+    def wait(self, ticket):
+        _check(lib().jb_wait(self._h, ticket), self._h)
+
+    # -- the seam, device buffers ------------------------------------------------------------
+    def blocks_to_rgb_device(self, batch, stream=None):
+        _check(lib().jb_blocks_to_rgb_device(self._h, ctypes.byref(batch), stream), self._h)
+
+    # -- decode(path) -> RGB -----------------------------------------------------------------
+    def decode_file(self, path):
+        p, w, h = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32()
+        _check(lib().jb_decode_file(self._h, os.fsencode(path), ctypes.byref(p), ctypes.byref(w), ctypes.byref(h)), self._h)
+        try:
+            n = w.value * h.value * 3
+            arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
+        finally:
+            lib().jb_free(p)
+        return arr.reshape(h.value, w.value, 3)
+
+
+def torch_batch(desc, n_images, coef_t, qtabs_t, rgb_t, rgb_row_stride=None, shared_qtabs=True):
+    """DeviceBatch over torch CUDA tensors (plumbing): coef_t int16 [n_images, n_blocks, 64],
+    qtabs_t int32 [3,64] (shared) or [n_images,3,64], rgb_t uint8 [n_images, H, row_stride]."""
+    b = DeviceBatch()
+    b.desc = desc
+    b.n_images = n_images
+    b.d_coef = coef_t.data_ptr()
+    b.coef_image_stride = coef_t.stride(0) * 2 if n_images > 1 else coef_t.numel() * 2
+    b.d_qtabs = qtabs_t.data_ptr()
+    b.qtab_image_stride = 0 if shared_qtabs else 768
+    b.d_rgb = rgb_t.data_ptr()
+    b.rgb_row_stride = rgb_row_stride or rgb_t.stride(1)
+    b.rgb_image_stride = rgb_t.stride(0)
+    return b

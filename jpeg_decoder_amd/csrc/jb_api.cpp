@@ -1,0 +1,334 @@
+// jb_api.cpp -- the C ABI of include/jpegblk.h over the HIP kernels of jb_kernels.hip.
+//
+// Host side of the seam dequantize(); inverseDCT(); YCbCrToRGB(); (reference
+// jpeg.cpp:786-788).  A jb_ctx owns one HIP stream and a ring of staging slots (device
+// coefficient / pixel buffers + a pinned quant-table block each) so that the copies and the
+// kernel of image i overlap the host Huffman stage of image i+1.  There is deliberately NO CPU
+// fallback here: without a usable HIP device every compute entry point fails with JB_ERR_HIP.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/jpegblk.h"
+#include "jb_kernels.h"
+
+namespace {
+
+thread_local std::string g_tls_error = "";
+
+struct Slot {
+  void *d_coef = nullptr;
+  void *d_rgb = nullptr;
+  int32_t *h_q = nullptr;  // pinned int32[3][64]
+  int32_t *d_q = nullptr;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+  int ticket = -1;
+};
+
+}  // namespace
+
+struct jb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
+  int n_slots = 0;
+  Slot slots[8];
+  int next_slot = 0;
+  int next_ticket = 1;
+  std::string error;
+};
+
+namespace {
+
+int fail(jb_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->error = buf;
+  g_tls_error = buf;
+  return code;
+}
+
+#define JB_HIP(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return fail(ctx, JB_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
+  int rc = jb_geometry_of(d, g);
+  if (rc == JB_ERR_NULL) return fail(ctx, rc, "null descriptor");
+  if (rc == JB_ERR_GEOMETRY) return fail(ctx, rc, "image size %dx%d outside 1..65535", d->width, d->height);
+  if (rc == JB_ERR_SAMPLING) return fail(ctx, rc, "luma sampling factors %dx%d not in {1,2}x{1,2}", d->hs, d->vs);
+  if (rc == JB_ERR_QTAB) return fail(ctx, rc, "quantisation table id outside 0..3");
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jb_abi_version(void) { return JB_ABI_VERSION; }
+
+int jb_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(nullptr, JB_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+// read_sof's derivations, reference jpeg.cpp:77-80 (block counts) and 110-127 (sampling checks,
+// padding of odd block counts when the luma factor is 2)
+int jb_geometry_of(const jb_image_desc *d, jb_geometry *g) {
+  if (!d || !g) return JB_ERR_NULL;
+  if (d->width < 1 || d->height < 1 || d->width > 65535 || d->height > 65535) return JB_ERR_GEOMETRY;
+  if ((d->hs != 1 && d->hs != 2) || (d->vs != 1 && d->vs != 2)) return JB_ERR_SAMPLING;
+  for (int i = 0; i < 3; i++)
+    if (d->qtab_id[i] < 0 || d->qtab_id[i] > 3) return JB_ERR_QTAB;
+  memset(g, 0, sizeof *g);
+  g->mcu_w = (d->width + 7) / 8;
+  g->mcu_h = (d->height + 7) / 8;
+  g->mcu_w_real = g->mcu_w + ((d->hs == 2 && (g->mcu_w & 1)) ? 1 : 0);
+  g->mcu_h_real = g->mcu_h + ((d->vs == 2 && (g->mcu_h & 1)) ? 1 : 0);
+  g->mcus_x = g->mcu_w_real / d->hs;
+  g->mcus_y = g->mcu_h_real / d->vs;
+  g->blocks_per_mcu = d->hs * d->vs + 2;
+  g->n_coded_blocks = (int64_t)g->mcus_x * g->mcus_y * g->blocks_per_mcu;
+  g->coef_bytes = g->n_coded_blocks * 128;
+  g->rgb_bytes = (int64_t)d->width * d->height * 3;
+  return JB_OK;
+}
+
+int jb_resolve_qtabs(const jb_image_desc *d, const uint16_t *qtabs, int32_t *out192) {
+  if (!d || !qtabs || !out192) return JB_ERR_NULL;
+  for (int c = 0; c < 3; c++) {
+    if (d->qtab_id[c] < 0 || d->qtab_id[c] > 3) return JB_ERR_QTAB;
+    // the table each component names (reference jpeg.cpp:584), natural order
+    for (int i = 0; i < 64; i++) out192[c * 64 + i] = qtabs[d->qtab_id[c] * 64 + i];
+  }
+  return JB_OK;
+}
+
+const char *jb_kernel_name(const jb_image_desc *d) {
+  if (!d) return "";
+  return jbk_kernel_name(d->hs, d->vs);
+}
+
+int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, int n_slots, jb_ctx **out) {
+  if (!out) return fail(nullptr, JB_ERR_NULL, "jb_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  JB_HIP(nullptr, hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev)
+    return fail(nullptr, JB_ERR_HIP, "device %d not available (%d HIP devices visible)", device_id, ndev);
+  if ((max_coef_bytes == 0) != (max_rgb_bytes == 0))
+    return fail(nullptr, JB_ERR_CAPACITY, "max_coef_bytes and max_rgb_bytes must both be zero or both non-zero");
+  if (n_slots < 1) n_slots = 1;
+  if (n_slots > 8) n_slots = 8;
+  jb_ctx *ctx = new (std::nothrow) jb_ctx();
+  if (!ctx) return fail(nullptr, JB_ERR_CAPACITY, "out of host memory");
+  ctx->device = device_id;
+  ctx->max_coef = max_coef_bytes;
+  ctx->max_rgb = max_rgb_bytes;
+  // device rows are padded to 16 B (kernel fast path needs 4-B aligned rows): <= 15 B per row
+  ctx->rgb_alloc = max_rgb_bytes ? max_rgb_bytes + 16u * 65536u : 0;
+  ctx->n_slots = max_coef_bytes ? n_slots : 0;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
+    Slot &s = ctx->slots[i];
+    e = hipMalloc(&s.d_coef, round_up((int64_t)max_coef_bytes, 256));
+    if (e == hipSuccess) e = hipMalloc(&s.d_rgb, ctx->rgb_alloc);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.d_q, 768);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_q, 768, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, JB_ERR_HIP, "jb_ctx_create: %s", hipGetErrorString(e));
+    jb_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return JB_OK;
+}
+
+void jb_ctx_destroy(jb_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 8; i++) {
+    Slot &s = ctx->slots[i];
+    if (s.d_coef) (void)hipFree(s.d_coef);
+    if (s.d_rgb) (void)hipFree(s.d_rgb);
+    if (s.d_q) (void)hipFree(s.d_q);
+    if (s.h_q) (void)hipHostFree(s.h_q);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *jb_last_error(const jb_ctx *ctx) { return ctx ? ctx->error.c_str() : g_tls_error.c_str(); }
+
+void *jb_ctx_stream(jb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int jb_ctx_synchronize(jb_ctx *ctx) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_synchronize: ctx is NULL");
+  JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return JB_OK;
+}
+
+int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_blocks_to_rgb_device: ctx is NULL");
+  if (!b || !b->d_coef || !b->d_qtabs || !b->d_rgb) return fail(ctx, JB_ERR_NULL, "jb_blocks_to_rgb_device: NULL pointer");
+  jb_geometry g;
+  int rc = check_desc(ctx, &b->desc, &g);
+  if (rc) return rc;
+  if (b->n_images < 1) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d", b->n_images);
+  if (b->rgb_row_stride < 3LL * b->desc.width)
+    return fail(ctx, JB_ERR_GEOMETRY, "rgb_row_stride %lld < 3*width", (long long)b->rgb_row_stride);
+  if (((uintptr_t)b->d_coef & 15) || (b->coef_image_stride & 15))
+    return fail(ctx, JB_ERR_GEOMETRY, "coefficient pointer and image stride must be multiples of 16 bytes");
+  if (((uintptr_t)b->d_qtabs & 3) || (b->qtab_image_stride & 3))
+    return fail(ctx, JB_ERR_GEOMETRY, "quant-table pointer and stride must be multiples of 4 bytes");
+  if (b->n_images > 1 && (b->coef_image_stride < g.coef_bytes || b->rgb_image_stride < b->rgb_row_stride * (int64_t)b->desc.height))
+    return fail(ctx, JB_ERR_GEOMETRY, "image strides smaller than one image");
+  const int per_tile = jbk_mcus_per_tile(b->desc.hs, b->desc.vs);
+  JbLaunch p;
+  memset(&p, 0, sizeof p);
+  p.coef = b->d_coef;
+  p.qtabs = b->d_qtabs;
+  p.rgb = b->d_rgb;
+  p.coef_image_stride = b->coef_image_stride;
+  p.qtab_image_stride = b->qtab_image_stride;
+  p.rgb_image_stride = b->rgb_image_stride;
+  p.rgb_row_stride = b->rgb_row_stride;
+  p.width = b->desc.width;
+  p.height = b->desc.height;
+  p.mcus_x = g.mcus_x;
+  p.mcus_y = g.mcus_y;
+  p.tiles_per_row = (g.mcus_x + per_tile - 1) / per_tile;
+  const int64_t n_tiles = (int64_t)b->n_images * g.mcus_y * p.tiles_per_row;
+  if (n_tiles > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "batch too large for one launch (%lld tiles)", (long long)n_tiles);
+  p.n_tiles = (int32_t)n_tiles;
+  p.fast_store = (((uintptr_t)b->d_rgb & 3) == 0 && (b->rgb_row_stride & 3) == 0 && (b->rgb_image_stride & 3) == 0) ? 1 : 0;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  JB_HIP(ctx, jbk_launch(p, b->desc.hs, b->desc.vs, s));
+  return JB_OK;
+}
+
+void *jb_pinned_alloc(size_t bytes) {
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    fail(nullptr, JB_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+void jb_pinned_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
+              uint8_t *rgb, int64_t rgb_stride, int *ticket) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_submit: ctx is NULL");
+  if (!desc || !coef || !qtabs || !rgb || !ticket) return fail(ctx, JB_ERR_NULL, "jb_submit: NULL pointer");
+  if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
+  jb_geometry g;
+  int rc = check_desc(ctx, desc, &g);
+  if (rc) return rc;
+  if (rgb_stride < 3LL * desc->width) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
+  const int64_t dev_stride = round_up(3LL * desc->width, 16);
+  if ((size_t)g.coef_bytes > ctx->max_coef || (size_t)(dev_stride * desc->height) > ctx->rgb_alloc ||
+      (size_t)g.rgb_bytes > ctx->max_rgb)
+    return fail(ctx, JB_ERR_CAPACITY, "image %dx%d exceeds the capacity the context was created with", desc->width, desc->height);
+  JB_HIP(ctx, hipSetDevice(ctx->device));
+  Slot &s = ctx->slots[ctx->next_slot];
+  if (s.busy) {  // ring full: wait for the oldest submission
+    JB_HIP(ctx, hipEventSynchronize(s.done));
+    s.busy = false;
+  }
+  rc = jb_resolve_qtabs(desc, qtabs, s.h_q);
+  if (rc) return fail(ctx, rc, "bad quantisation table id");
+  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768, hipMemcpyHostToDevice, ctx->stream));
+  JB_HIP(ctx, hipMemcpyAsync(s.d_coef, coef, (size_t)g.coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+  jb_device_batch b;
+  memset(&b, 0, sizeof b);
+  b.desc = *desc;
+  b.n_images = 1;
+  b.d_coef = (const int16_t *)s.d_coef;
+  b.coef_image_stride = round_up(g.coef_bytes, 16);
+  b.d_qtabs = s.d_q;
+  b.qtab_image_stride = 0;
+  b.d_rgb = (uint8_t *)s.d_rgb;
+  b.rgb_row_stride = dev_stride;
+  b.rgb_image_stride = dev_stride * desc->height;
+  rc = jb_blocks_to_rgb_device(ctx, &b, ctx->stream);
+  if (rc) return rc;
+  JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                               (size_t)desc->height, hipMemcpyDeviceToHost, ctx->stream));
+  JB_HIP(ctx, hipEventRecord(s.done, ctx->stream));
+  s.busy = true;
+  s.ticket = ctx->next_ticket++;
+  if (ctx->next_ticket < 0) ctx->next_ticket = 1;
+  *ticket = s.ticket;
+  ctx->next_slot = (ctx->next_slot + 1) % ctx->n_slots;
+  return JB_OK;
+}
+
+int jb_wait(jb_ctx *ctx, int ticket) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_wait: ctx is NULL");
+  for (int i = 0; i < ctx->n_slots; i++) {
+    Slot &s = ctx->slots[i];
+    if (s.ticket == ticket) {
+      if (s.busy) {
+        JB_HIP(ctx, hipEventSynchronize(s.done));
+        s.busy = false;
+      }
+      return JB_OK;
+    }
+  }
+  return fail(ctx, JB_ERR_STATE, "ticket %d is not in flight (already waited for and its slot reused?)", ticket);
+}
+
+int jb_blocks_to_rgb(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
+                     uint8_t *rgb, int64_t rgb_stride) {
+  int ticket = -1;
+  int rc = jb_submit(ctx, desc, coef, qtabs, rgb, rgb_stride, &ticket);
+  if (rc) return rc;
+  return jb_wait(ctx, ticket);
+}
+
+void jb_free(void *p) { free(p); }
+
+int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height, int64_t rgb_stride) {
+  if (!path || !rgb) return fail(nullptr, JB_ERR_NULL, "jb_write_ppm: NULL pointer");
+  if (width < 1 || height < 1 || rgb_stride < 3LL * width) return fail(nullptr, JB_ERR_GEOMETRY, "jb_write_ppm: bad geometry");
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(nullptr, JB_ERR_FORMAT, "cannot open %s for writing", path);
+  fprintf(f, "P6\n%d %d\n255\n", width, height);
+  for (int y = 0; y < height; y++)
+    if (fwrite(rgb + (int64_t)y * rgb_stride, 1, (size_t)width * 3, f) != (size_t)width * 3) {
+      fclose(f);
+      return fail(nullptr, JB_ERR_FORMAT, "short write to %s", path);
+    }
+  fclose(f);
+  return JB_OK;
+}
+
+}  // extern "C"
+
+// used by jb_frontend.cpp to report through the same channel
+int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%s", msg); }

@@ -1,0 +1,436 @@
+// jb_frontend.cpp -- host front end: JFIF marker parser + baseline Huffman decoder.
+//
+// This is the part of the reference that STAYS on the host (reference jpeg.cpp:67-446 and
+// 826-907, include/file.hpp, include/huffman.hpp).  It produces exactly what the reference's
+// decodeHuffman() produces (jpeg.cpp:405-446): de-zigzagged integer coefficient blocks in
+// MCU-interleaved scan order -- here packed as int16 straight into a caller buffer (pinned
+// memory when it comes from jb_pinned_alloc) that is handed to the device seam.
+//
+// Written table-driven (9-bit lookahead + canonical fallback, 64-bit bit buffer) instead of
+// the reference's bit-at-a-time linear code search (jpeg.cpp:300-320) and its per-byte heap
+// allocation (file.hpp:26-52); the decoded integers are identical.
+//
+// Behaviour kept from the reference: baseline SOF0 only (SOF2 -> unsupported, jpeg.cpp:69-73),
+// exactly 3 components (jpeg.cpp:83-87), luma factors in {1,2}, chroma 1x1 (jpeg.cpp:110-136),
+// table ids 0..3, one scan with Ss=0, Se=63, Ah=Al=0 (jpeg.cpp:255-264), APPn/COM ignored
+// (file.hpp:201-207).  Deliberate differences, outside the reference's working domain:
+//  * errors are returned (jb_status), never exit(1);
+//  * 16-bit quantisation tables keep all 16 bits (the reference keeps the low byte only,
+//    jpeg.cpp:216 -- no bundled image has one);
+//  * restart intervals are counted in MCUs as ITU-T T.81 says; the reference's test
+//    (jpeg.cpp:414,419) agrees with that only when an interval is a whole number of MCU rows
+//    (true for its bundled images/img4.jpg: interval 100 = one row).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/jpegblk.h"
+
+struct jb_ctx;
+int jb_fail_(jb_ctx *ctx, int code, const char *msg);
+
+namespace {
+
+// zig-zag position -> natural index (ITU-T T.81 Figure A.6; reference types.hpp:23-31)
+const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                             12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                             58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffTable {
+  bool set = false;
+  uint8_t counts[17] = {0};
+  uint8_t symbols[256] = {0};
+  // canonical decode (reference huffman.hpp:17-29 generates the same codes)
+  int32_t maxcode[18];
+  int32_t valptr[17];
+  int32_t mincode[17];
+  // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
+  uint16_t fast[512];
+
+  bool build() {
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; len++) {
+      valptr[len] = k;
+      mincode[len] = code;
+      k += counts[len];
+      code += counts[len];
+      maxcode[len] = counts[len] ? code - 1 : -1;
+      if (code > (1 << len)) return false;  // over-subscribed
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+    memset(fast, 0, sizeof fast);
+    code = 0;
+    k = 0;
+    for (int len = 1; len <= 9; len++) {
+      for (int i = 0; i < counts[len]; i++, k++, code++) {
+        const int first = code << (9 - len);
+        for (int j = 0; j < (1 << (9 - len)); j++) fast[first + j] = (uint16_t)((len << 8) | symbols[k]);
+      }
+      code <<= 1;
+    }
+    set = true;
+    return true;
+  }
+};
+
+struct Frame {
+  jb_image_desc desc;
+  bool have_sof = false;
+  uint16_t qtabs[4][64];
+  bool qset[4] = {false, false, false, false};
+  HuffTable dc[4], ac[4];
+  int comp_id[3] = {0, 0, 0};
+  int dc_id[3] = {0, 0, 0}, ac_id[3] = {0, 0, 0};
+  int restart_interval = 0;
+  const uint8_t *scan = nullptr;  // first entropy-coded byte
+  size_t scan_len = 0;            // bytes up to the end of the buffer
+};
+
+struct Err {
+  int code = JB_OK;
+  std::string msg;
+};
+
+int set_err(Err &e, int code, const char *msg) {
+  e.code = code;
+  e.msg = msg;
+  return code;
+}
+
+// MSB-first bit reader over the stuffed scan bytes: FF00 -> FF, a marker stops the stream
+// (zero bits are supplied past it).  Reference equivalent: readImageData + BitStream
+// (file.hpp:59-104, 130-164).
+struct BitReader {
+  const uint8_t *p, *end;
+  uint64_t acc = 0;
+  int nbits = 0;
+  int marker = 0;  // pending marker byte (0 = none)
+  int pad = 0;     // zero bytes supplied past a marker / the end of the data
+
+  BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+
+  inline void refill() {
+    while (nbits <= 56) {
+      uint32_t byte = 0;
+      if (!marker && p < end) {
+        byte = *p++;
+        if (byte == 0xff) {
+          while (p < end && *p == 0xff) p++;  // fill bytes (reference file.hpp:88-91)
+          const uint8_t m = p < end ? *p++ : 0xd9;
+          if (m == 0) byte = 0xff;
+          else {
+            marker = m;
+            byte = 0;
+            pad++;
+          }
+        }
+      } else {
+        pad++;
+      }
+      acc |= (uint64_t)byte << (56 - nbits);
+      nbits += 8;
+    }
+  }
+  inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+  inline void drop(int n) {
+    acc <<= n;
+    nbits -= n;
+  }
+  inline uint32_t get(int n) {
+    if (n == 0) return 0;
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  // restart boundary: discard the partial byte, step over the RSTn marker
+  // (reference: BitStream::align, file.hpp:161-164, after readImageData dropped the marker)
+  // true when bits past the real data (padding zeros) have been consumed: truncated/corrupt
+  bool overran() const { return pad * 8 > nbits; }
+  bool restart() {
+    if (overran()) return false;
+    pad = 0;
+    if (!marker) {
+      // marker not reached by the lookahead yet: the remaining buffered bits are padding;
+      // scan forward to it
+      acc = 0;
+      nbits = 0;
+      while (p + 1 < end && !(p[0] == 0xff && p[1] >= 0xd0 && p[1] <= 0xd7)) p++;
+      if (p + 1 >= end) return false;
+      p += 2;
+      return true;
+    }
+    if (marker < 0xd0 || marker > 0xd7) return false;
+    marker = 0;
+    acc = 0;
+    nbits = 0;
+    return true;
+  }
+};
+
+inline int decode_symbol(BitReader &br, const HuffTable &t) {
+  br.refill();
+  const uint32_t look = br.peek(9);
+  const uint16_t f = t.fast[look];
+  if (f) {
+    br.drop(f >> 8);
+    return f & 0xff;
+  }
+  int32_t code = (int32_t)br.peek(10);
+  int len = 10;
+  while (len <= 16 && code > t.maxcode[len]) {
+    len++;
+    code = (int32_t)br.peek(len);
+  }
+  if (len > 16) return -1;
+  br.drop(len);
+  return t.symbols[t.valptr[len] + code - t.mincode[len]];
+}
+
+inline int extend(uint32_t v, int n) {
+  // T.81 F.2.2.1 EXTEND; reference jpeg.cpp:340-343, 394-397
+  return (int)v < (1 << (n - 1)) ? (int)v - (1 << n) + 1 : (int)v;
+}
+
+// one block, reference decodeMCUComponent (jpeg.cpp:322-403)
+inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac, int &pred, int16_t *out) {
+  memset(out, 0, 128);
+  const int s = decode_symbol(br, dc);
+  if (s < 0 || s > 11) return false;
+  br.refill();
+  const int diff = s ? extend(br.get(s), s) : 0;
+  pred += diff;
+  if (pred < -32768 || pred > 32767) return false;
+  out[0] = (int16_t)pred;
+  int k = 1;
+  while (k < 64) {
+    const int rs = decode_symbol(br, ac);
+    if (rs < 0) return false;
+    if (rs == 0) break;  // EOB
+    int r = rs >> 4;
+    const int n = rs & 15;
+    if (rs == 0xf0) r = 16;
+    if (k + r >= 64 || n > 10) return false;  // reference jpeg.cpp:372-385
+    k += r;
+    if (n) {
+      br.refill();
+      out[kZigZag[k]] = (int16_t)extend(br.get(n), n);
+      k++;
+    }
+  }
+  return true;
+}
+
+int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
+  if (!d || n < 4 || d[0] != 0xff || d[1] != 0xd8) return set_err(e, JB_ERR_FORMAT, "not a JPEG file (no SOI)");
+  size_t pos = 2;
+  memset(fr.qtabs, 0, sizeof fr.qtabs);
+  while (true) {
+    if (pos + 1 >= n) return set_err(e, JB_ERR_FORMAT, "truncated file (no SOS)");
+    if (d[pos] != 0xff) return set_err(e, JB_ERR_FORMAT, "marker expected");
+    while (pos < n && d[pos] == 0xff) pos++;
+    if (pos >= n) return set_err(e, JB_ERR_FORMAT, "truncated file");
+    const uint8_t m = d[pos++];
+    if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;  // no payload
+    if (m == 0xd9) return set_err(e, JB_ERR_FORMAT, "EOI before SOS");
+    if (pos + 2 > n) return set_err(e, JB_ERR_FORMAT, "truncated segment");
+    const size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+    if (len < 2 || pos + len > n) return set_err(e, JB_ERR_FORMAT, "bad segment length");
+    const uint8_t *s = d + pos + 2;
+    const size_t sl = len - 2;
+    pos += len;
+    if (m == 0xdb) {  // DQT, reference jpeg.cpp:197-231
+      size_t i = 0;
+      while (i < sl) {
+        const int pq = s[i] >> 4, tq = s[i] & 15;
+        i++;
+        if (tq > 3) return set_err(e, JB_ERR_QTAB, "quantisation table id > 3");
+        const size_t need = pq ? 128 : 64;
+        if (pq > 1 || i + need > sl) return set_err(e, JB_ERR_FORMAT, "bad DQT segment");
+        for (int k = 0; k < 64; k++) {
+          const uint16_t v = pq ? (uint16_t)((s[i + 2 * k] << 8) | s[i + 2 * k + 1]) : s[i + k];
+          fr.qtabs[tq][kZigZag[k]] = v;  // stored de-zigzagged, reference types.hpp:88-90
+        }
+        fr.qset[tq] = true;
+        i += need;
+      }
+    } else if (m == 0xc0) {  // SOF0, reference jpeg.cpp:67-146
+      if (sl < 6) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
+      if (s[0] != 8) return set_err(e, JB_ERR_UNSUPPORTED, "only 8-bit precision is supported");
+      fr.desc.height = (s[1] << 8) | s[2];
+      fr.desc.width = (s[3] << 8) | s[4];
+      if (s[5] != 3) return set_err(e, JB_ERR_UNSUPPORTED, "only 3 components are supported");
+      if (sl < 6 + 9) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
+      for (int c = 0; c < 3; c++) {
+        fr.comp_id[c] = s[6 + 3 * c];
+        const int h = s[7 + 3 * c] >> 4, v = s[7 + 3 * c] & 15;
+        const int tq = s[8 + 3 * c];
+        if (tq > 3) return set_err(e, JB_ERR_QTAB, "quantisation table id > 3");
+        fr.desc.qtab_id[c] = tq;
+        if (c == 0) {
+          if ((h != 1 && h != 2) || (v != 1 && v != 2)) return set_err(e, JB_ERR_SAMPLING, "luma sampling factors must be 1 or 2");
+          fr.desc.hs = h;
+          fr.desc.vs = v;
+        } else if (h != 1 || v != 1) {
+          return set_err(e, JB_ERR_SAMPLING, "chroma sampling factors must be 1x1");
+        }
+      }
+      fr.desc.reserved = 0;
+      if (fr.desc.width < 1 || fr.desc.height < 1) return set_err(e, JB_ERR_GEOMETRY, "empty image");
+      fr.have_sof = true;
+    } else if (m == 0xc2) {
+      return set_err(e, JB_ERR_UNSUPPORTED, "progressive JPEG is not supported");  // jpeg.cpp:69-73
+    } else if (m >= 0xc1 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+      return set_err(e, JB_ERR_UNSUPPORTED, "only baseline (SOF0) frames are supported");
+    } else if (m == 0xc4) {  // DHT, reference jpeg.cpp:148-196
+      size_t i = 0;
+      while (i < sl) {
+        if (i + 17 > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        if (th > 3 || tc > 1) return set_err(e, JB_ERR_FORMAT, "bad Huffman table id");
+        HuffTable &t = tc ? fr.ac[th] : fr.dc[th];
+        int total = 0;
+        t.counts[0] = 0;
+        for (int l = 1; l <= 16; l++) {
+          t.counts[l] = s[i + l];
+          total += s[i + l];
+        }
+        i += 17;
+        if (total > 256 || i + total > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
+        memcpy(t.symbols, s + i, total);
+        i += total;
+        if (!t.build()) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
+      }
+    } else if (m == 0xdd) {  // DRI, reference jpeg.cpp:289-298
+      if (sl != 2) return set_err(e, JB_ERR_FORMAT, "bad DRI segment");
+      fr.restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xda) {  // SOS, reference jpeg.cpp:233-287
+      if (!fr.have_sof) return set_err(e, JB_ERR_FORMAT, "SOS before SOF");
+      if (sl < 1 || s[0] != 3) return set_err(e, JB_ERR_UNSUPPORTED, "only 3-component scans are supported");
+      if (sl != 1 + 6 + 3) return set_err(e, JB_ERR_FORMAT, "bad SOS length");
+      for (int c = 0; c < 3; c++) {
+        if (s[1 + 2 * c] != fr.comp_id[c]) return set_err(e, JB_ERR_UNSUPPORTED, "scan component order differs from frame");
+        fr.dc_id[c] = s[2 + 2 * c] >> 4;
+        fr.ac_id[c] = s[2 + 2 * c] & 15;
+        if (fr.dc_id[c] > 3 || fr.ac_id[c] > 3) return set_err(e, JB_ERR_FORMAT, "bad Huffman table id in SOS");
+      }
+      if (s[7] != 0 || s[8] != 63) return set_err(e, JB_ERR_UNSUPPORTED, "spectral selection must be 0..63");
+      if (s[9] != 0) return set_err(e, JB_ERR_UNSUPPORTED, "successive approximation must be 0");
+      // process_image_data's table checks, reference jpeg.cpp:757-774
+      for (int c = 0; c < 3; c++) {
+        if (!fr.qset[fr.desc.qtab_id[c]]) return set_err(e, JB_ERR_QTAB, "quantisation table not found");
+        if (!fr.dc[fr.dc_id[c]].set) return set_err(e, JB_ERR_FORMAT, "Huffman DC table not found");
+        if (!fr.ac[fr.ac_id[c]].set) return set_err(e, JB_ERR_FORMAT, "Huffman AC table not found");
+      }
+      fr.scan = d + pos;
+      fr.scan_len = n - pos;
+      return JB_OK;
+    }
+    // APPn (E0-EF), COM (FE), anything else with a length: ignored (reference file.hpp:201-207)
+  }
+}
+
+// reference decodeHuffman (jpeg.cpp:405-446): MCUs in raster order, per MCU hs*vs luma blocks
+// (v-major), Cb, Cr; DC predictors reset at restart boundaries
+int decode_scan(const Frame &fr, const jb_geometry &g, int16_t *coef, Err &e) {
+  BitReader br(fr.scan, fr.scan + fr.scan_len);
+  int pred[3] = {0, 0, 0};
+  const int ny = fr.desc.hs * fr.desc.vs;
+  const int64_t n_mcus = (int64_t)g.mcus_x * g.mcus_y;
+  int until_restart = fr.restart_interval;
+  int16_t *out = coef;
+  for (int64_t m = 0; m < n_mcus; m++) {
+    if (fr.restart_interval && until_restart == 0) {
+      if (!br.restart()) return set_err(e, JB_ERR_FORMAT, "restart marker missing");
+      pred[0] = pred[1] = pred[2] = 0;
+      until_restart = fr.restart_interval;
+    }
+    for (int b = 0; b < ny + 2; b++) {
+      const int c = b < ny ? 0 : b - ny + 1;
+      if (!decode_block(br, fr.dc[fr.dc_id[c]], fr.ac[fr.ac_id[c]], pred[c], out))
+        return set_err(e, JB_ERR_FORMAT, "corrupt entropy-coded data");
+      out += 64;
+    }
+    until_restart--;
+  }
+  if (br.overran()) return set_err(e, JB_ERR_FORMAT, "entropy-coded data ends early");
+  return JB_OK;
+}
+
+int report(jb_ctx *ctx, const Err &e) { return jb_fail_(ctx, e.code, e.msg.c_str()); }
+
+}  // namespace
+
+extern "C" {
+
+int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc, uint16_t *qtabs,
+                      int16_t *coef, size_t coef_cap_bytes) {
+  if (!jpeg || !desc) return jb_fail_(nullptr, JB_ERR_NULL, "jb_entropy_decode: NULL pointer");
+  Frame *fr = new Frame();
+  Err e;
+  int rc = parse_headers(jpeg, jpeg_bytes, *fr, e);
+  if (rc == JB_OK) {
+    *desc = fr->desc;
+    if (qtabs) memcpy(qtabs, fr->qtabs, sizeof fr->qtabs);
+    if (coef) {
+      jb_geometry g;
+      rc = jb_geometry_of(&fr->desc, &g);
+      if (rc) set_err(e, rc, "bad frame geometry");
+      else if ((size_t)g.coef_bytes > coef_cap_bytes) rc = set_err(e, JB_ERR_CAPACITY, "coefficient buffer too small");
+      else rc = decode_scan(*fr, g, coef, e);
+    }
+  }
+  delete fr;
+  return rc ? report(nullptr, e) : JB_OK;
+}
+
+int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t **rgb, int32_t *width,
+                     int32_t *height) {
+  if (!ctx) return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_memory: ctx is NULL");
+  if (!jpeg || !rgb || !width || !height) return jb_fail_(ctx, JB_ERR_NULL, "jb_decode_memory: NULL pointer");
+  *rgb = nullptr;
+  jb_image_desc desc;
+  uint16_t qtabs[256];
+  int rc = jb_entropy_decode(jpeg, jpeg_bytes, &desc, qtabs, nullptr, 0);
+  if (rc) return jb_fail_(ctx, rc, jb_last_error(nullptr));
+  jb_geometry g;
+  rc = jb_geometry_of(&desc, &g);
+  if (rc) return jb_fail_(ctx, rc, "bad frame geometry");
+  int16_t *coef = (int16_t *)jb_pinned_alloc((size_t)g.coef_bytes);
+  if (!coef) return jb_fail_(ctx, JB_ERR_HIP, jb_last_error(nullptr));
+  rc = jb_entropy_decode(jpeg, jpeg_bytes, &desc, qtabs, coef, (size_t)g.coef_bytes);
+  uint8_t *out = nullptr;
+  if (rc) jb_fail_(ctx, rc, jb_last_error(nullptr));
+  else {
+    out = (uint8_t *)malloc((size_t)g.rgb_bytes);
+    if (!out) rc = jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
+    else rc = jb_blocks_to_rgb(ctx, &desc, coef, qtabs, out, 3LL * desc.width);
+  }
+  jb_pinned_free(coef);
+  if (rc) {
+    free(out);
+    return rc;
+  }
+  *rgb = out;
+  *width = desc.width;
+  *height = desc.height;
+  return JB_OK;
+}
+
+int jb_decode_file(jb_ctx *ctx, const char *path, uint8_t **rgb, int32_t *width, int32_t *height) {
+  if (!ctx) return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_file: ctx is NULL");
+  if (!path) return jb_fail_(ctx, JB_ERR_NULL, "jb_decode_file: path is NULL");
+  FILE *f = fopen(path, "rb");
+  if (!f) return jb_fail_(ctx, JB_ERR_FORMAT, (std::string("cannot open ") + path).c_str());
+  std::vector<uint8_t> buf;
+  uint8_t chunk[1 << 16];
+  size_t got;
+  while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) buf.insert(buf.end(), chunk, chunk + got);
+  fclose(f);
+  return jb_decode_memory(ctx, buf.data(), buf.size(), rgb, width, height);
+}
+
+}  // extern "C"

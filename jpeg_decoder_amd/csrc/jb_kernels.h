@@ -1,0 +1,28 @@
+// jb_kernels.h -- internal interface between the C-ABI layer (jb_api.cpp) and the HIP
+// kernels (jb_kernels.hip).  Not part of the public ABI (include/jpegblk.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+// Kernel arguments of one launch: a batch of images of identical geometry.
+struct JbLaunch {
+  const int16_t *coef;        // device; decode-order int16 blocks
+  const int32_t *qtabs;       // device; per image int32[3][64] (Y, Cb, Cr), natural order
+  uint8_t *rgb;               // device; interleaved RGB
+  int64_t coef_image_stride;  // bytes
+  int64_t qtab_image_stride;  // bytes (0 = tables shared by the batch)
+  int64_t rgb_image_stride;   // bytes
+  int64_t rgb_row_stride;     // bytes
+  int32_t width, height;      // pixels
+  int32_t mcus_x, mcus_y;     // coded MCUs per row / column
+  int32_t tiles_per_row;      // ceil(mcus_x / jbk_mcus_per_tile(hs, vs))
+  int32_t n_tiles;            // n_images * mcus_y * tiles_per_row = workgroups launched
+  int32_t fast_store;         // 1 when rgb base and every stride are multiples of 4 bytes
+  int32_t reserved;
+};
+
+// MCUs covered by one workgroup (a tile is always 192 coded blocks): 64 / 48 / 32.
+int jbk_mcus_per_tile(int hs, int vs);
+// Launch the fused kernel for luma sampling (hs, vs): one 192-lane workgroup per tile.
+hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream);
+const char *jbk_kernel_name(int hs, int vs);

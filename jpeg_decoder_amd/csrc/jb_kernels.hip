@@ -1,0 +1,323 @@
+// jb_kernels.hip -- fused dequantize -> 8x8 inverse DCT -> YCbCr->RGB for gfx950 (MI355X).
+//
+// Replaces the three whole-image passes of the reference (dequantize(), inverseDCT(),
+// YCbCrToRGB(): jpeg.cpp:572-590, 735-753, 544-561) with ONE kernel that reads every
+// coefficient once and writes every pixel once.
+//
+// Work decomposition (wave64, no MFMA -- this is 8-point butterflies, not a GEMM):
+//   * a workgroup (3 waves, 192 lanes) owns one TILE = a run of 192/NB consecutive MCUs of one
+//     MCU row (NB = hs*vs + 2 coded blocks per MCU): 64 MCUs in 4:4:4, 32 in 4:2:0, 48 in
+//     4:2:2 / 4:4:0 -- always 192 coded blocks = 24 KiB of contiguous int16 coefficients in,
+//     192*64 luma-resolution... pixels out.
+//   * stage 1, HBM -> LDS: the tile's coefficient bytes are copied by 8 rounds of
+//     global_load_lds_dwordx4 (LDS-DMA: no VGPRs, 1 KiB contiguous per wave-instruction, whole
+//     128-B lines).  The 16-B chunks of block n land at chunk position j ^ ((n>>1)&7) -- the
+//     swizzle is applied to the per-lane GLOBAL source address because LDS-DMA writes LDS
+//     linearly -- so that the 128-B-strided ds_read_b128 of stage 2 is bank-conflict free.
+//   * stage 2, one lane = one coded 8x8 block: 8 ds_read_b128 fetch the block, then dequantise
+//     and 16 1-D AAN passes run entirely in that lane's registers with static indexing (no
+//     cross-lane traffic, no redundant arithmetic).  The integer-valued result is written as
+//     f32 into planar image strips in LDS (Y strip 8*vs rows, Cb and Cr strips 8 rows; 48 KiB,
+//     overlaying the consumed coefficient bytes).
+//   * stage 3, one lane = 4 horizontally adjacent pixels: ds_read_b128 of Y, the (replicated)
+//     chroma samples, the colour transform, pack to 12 bytes and ONE global_store_dwordx3;
+//     consecutive lanes are consecutive in the image row, so a wave-instruction writes 768
+//     contiguous bytes (six whole 128-B lines).
+//
+// Arithmetic is bit-exact with the reference: int32 dequantise (v_mul_i32_i24), the AAN graph
+// of jpeg.cpp:598-662 evaluated in the same order with separate IEEE mul/add (this TU is built
+// with -ffp-contract=off), truncation toward zero after each 1-D pass (v_trunc_f32: equal to the
+// reference's float->int->float round trip for |x| < 2^31), colour per jpeg.cpp:521-535.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jb_kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(float, bits); }
+
+// f32 constants of reference include/types.hpp:5-19 (m*, s*) and jpeg.cpp:521-523, by bit pattern
+#define JB_M1 kf(0x3FB504F3u)
+#define JB_M2 kf(0x3F8A8BD4u)
+#define JB_M3 kf(0x3FB504F3u)
+#define JB_M4 kf(0x40273D74u)
+#define JB_M5 kf(0x3F43EF15u)
+#define JB_S0 kf(0x3EB504F3u)
+#define JB_S1 kf(0x3EFB14BEu)
+#define JB_S2 kf(0x3EEC835Eu)
+#define JB_S3 kf(0x3ED4DB31u)
+#define JB_S4 kf(0x3EB504F3u)
+#define JB_S5 kf(0x3E8E39DAu)
+#define JB_S6 kf(0x3E43EF15u)
+#define JB_S7 kf(0x3DC7C5C2u)
+#define JB_CR_R kf(0x3FB374BCu)
+#define JB_CB_G kf(0x3EB020C5u)
+#define JB_CR_G kf(0x3F36C8B4u)
+#define JB_CB_B kf(0x3FE2D0E5u)
+
+constexpr int kTileBlocks = 192;                  // coded blocks per tile = lanes per workgroup
+constexpr int kRawBytes = kTileBlocks * 128;      // 24 KiB of int16 coefficients
+constexpr int kPlaneBytes = kTileBlocks * 256;    // 48 KiB of f32 samples
+constexpr int kQtabOffset = kPlaneBytes;          // int32[3][64] after the planes
+constexpr int kLdsBytes = kPlaneBytes + 3 * 256;
+
+// One 1-D pass of the AAN network (reference jpeg.cpp:598-662 / 666-730), in place, each
+// output truncated toward zero exactly where the reference stores a float into an int.
+__device__ __forceinline__ void aan_1d(float &x0, float &x1, float &x2, float &x3, float &x4,
+                                       float &x5, float &x6, float &x7) {
+  const float g0 = x0 * JB_S0;
+  const float g1 = x4 * JB_S4;
+  const float g2 = x2 * JB_S2;
+  const float g3 = x6 * JB_S6;
+  const float g4 = x5 * JB_S5;
+  const float g5 = x1 * JB_S1;
+  const float g6 = x7 * JB_S7;
+  const float g7 = x3 * JB_S3;
+
+  const float f4 = g4 - g7;
+  const float f5 = g5 + g6;
+  const float f6 = g5 - g6;
+  const float f7 = g4 + g7;
+
+  const float e2 = g2 - g3;
+  const float e3 = g2 + g3;
+  const float e5 = f5 - f7;
+  const float e7 = f5 + f7;
+  const float e8 = f4 + f6;
+
+  const float d2 = e2 * JB_M1;
+  const float d4 = f4 * JB_M2;
+  const float d5 = e5 * JB_M3;
+  const float d6 = f6 * JB_M4;
+  const float d8 = e8 * JB_M5;
+
+  const float c0 = g0 + g1;
+  const float c1 = g0 - g1;
+  const float c2 = d2 - e3;
+  const float c4 = d4 + d8;
+  const float c5 = d5 + e7;
+  const float c6 = d6 - d8;
+  const float c8 = c5 - c6;
+
+  const float b0 = c0 + e3;
+  const float b1 = c1 + c2;
+  const float b2 = c1 - c2;
+  const float b3 = c0 - e3;
+  const float b4 = c4 - c8;
+  const float b6 = c6 - e7;
+
+  x0 = __builtin_truncf(b0 + e7);
+  x1 = __builtin_truncf(b1 + b6);
+  x2 = __builtin_truncf(b2 + c8);
+  x3 = __builtin_truncf(b3 + b4);
+  x4 = __builtin_truncf(b3 - b4);
+  x5 = __builtin_truncf(b2 - c8);
+  x6 = __builtin_truncf(b1 - b6);
+  x7 = __builtin_truncf(b0 - e7);
+}
+
+__device__ __forceinline__ uint32_t pack_u8(float x, uint32_t byte, uint32_t old) {
+  // reference jpeg.cpp:521-535: truncate to int, then clamp to 0..255; the value handed to the
+  // converter is already an integer in range, so its rounding mode is irrelevant
+  const float t = __builtin_amdgcn_fmed3f(__builtin_truncf(x), 0.0f, 255.0f);
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, byte, old);
+}
+
+struct __attribute__((packed, aligned(4))) dw3_t {
+  uint32_t x, y, z;
+};
+
+}  // namespace
+
+// One workgroup (192 lanes) per tile.  See the file header for the three stages.
+template <int HS, int VS>
+__global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
+  constexpr int NY = HS * VS;
+  constexpr int NB = NY + 2;
+  constexpr int MCUS = kTileBlocks / NB;        // MCUs per tile
+  constexpr int YW = MCUS * 8 * HS;             // luma strip width in pixels
+  constexpr int CW = MCUS * 8;                  // chroma strip width in samples
+  constexpr int YROWS = 8 * VS;
+  constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
+  constexpr int CR_OFF = CB_OFF + 8 * CW * 4;
+  static_assert(CR_OFF + 8 * CW * 4 == kPlaneBytes, "strips must fill the plane area exactly");
+
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- which tile (all wave-uniform) ----
+  const int tiles_per_image = p.tiles_per_row * p.mcus_y;
+  const int tile = blockIdx.x;
+  const int img = tile / tiles_per_image;
+  const int rem = tile - img * tiles_per_image;
+  const int my = rem / p.tiles_per_row;
+  const int mx0 = (rem - my * p.tiles_per_row) * MCUS;
+  const int nvalid = min(MCUS, p.mcus_x - mx0);
+  const int last_block = nvalid * NB - 1;
+  const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride +
+                             ((int64_t)my * p.mcus_x + mx0) * (NB * 128);
+  const int32_t *qsrc = (const int32_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
+
+  // ---- stage 1: coefficients HBM -> LDS by LDS-DMA, swizzled; quant tables -> LDS ----
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int ci = i * kTileBlocks + tid;  // 16-B chunk index within the tile
+    const int n = ci >> 3;                 // block the chunk position belongs to
+    const int f = (n >> 1) & 7;
+    const int nsrc = min(n, last_block);   // lanes past a ragged tile re-read its last block
+    const uint8_t *src = tile_coef + nsrc * 128 + (((ci & 7) ^ f) << 4);
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(lds + (i * kTileBlocks + wave * 64) * 16),
+                                     16, 0, 0);
+  }
+  *(int32_t *)(lds + kQtabOffset + tid * 4) = qsrc[tid];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- stage 2: this lane's block -> registers ----
+  const int n = tid;           // block index within the tile, decode order
+  const int mcu = n / NB;      // MCU within the tile
+  const int slot = n - mcu * NB;
+  const int comp = slot < NY ? 0 : slot - NY + 1;
+  float v[64];
+  {
+    uint32_t raw[32];
+    const int f = (n >> 1) & 7;
+    const char *base = lds + n * 128;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint4 t = *(const uint4 *)(base + ((j ^ f) << 4));
+      raw[j * 4 + 0] = t.x;
+      raw[j * 4 + 1] = t.y;
+      raw[j * 4 + 2] = t.z;
+      raw[j * 4 + 3] = t.w;
+    }
+    const int4 *q = (const int4 *)(lds + kQtabOffset + comp * 256);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int4 qa = q[k * 2], qb = q[k * 2 + 1];
+      const int qq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t w = raw[k * 4 + (i >> 1)];
+        const int c = (i & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+        // reference jpeg.cpp:567: int32 product; int->float on first use (jpeg.cpp:598)
+        v[k * 8 + i] = (float)__mul24(c, qq[i]);
+      }
+    }
+  }
+  __syncthreads();  // every lane holds its block: the coefficient bytes may be overwritten
+
+#pragma unroll
+  for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
+    aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
+           v[6 * 8 + i], v[7 * 8 + i]);
+#pragma unroll
+  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
+    aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
+           v[k * 8 + 6], v[k * 8 + 7]);
+
+  {
+    // strip address of this block's row 0: luma block (bv,bh) of MCU m sits at rows 8*bv..,
+    // columns (m*HS + bh)*8..; chroma blocks at columns m*8..
+    int off, pitch;
+    if (comp == 0) {
+      const int bv = slot / HS, bh = slot - bv * HS;
+      pitch = YW * 4;
+      off = (bv * 8) * pitch + (mcu * HS + bh) * 32;
+    } else {
+      pitch = CW * 4;
+      off = (comp == 1 ? CB_OFF : CR_OFF) + mcu * 32;
+    }
+    char *dst = lds + off;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      *(float4 *)(dst + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+      *(float4 *)(dst + k * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 3: colour transform + store, one lane = 4 adjacent pixels of one row ----
+  constexpr int TASKS_PER_ROW = YW / 4;
+  constexpr int TASKS = YROWS * TASKS_PER_ROW;
+  const int tile_x0 = mx0 * 8 * HS;
+  const int tile_y0 = my * 8 * VS;
+  uint8_t *img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  for (int t = tid; t < TASKS; t += kTileBlocks) {
+    const int row = t / TASKS_PER_ROW;
+    const int xq = t - row * TASKS_PER_ROW;
+    const int x = tile_x0 + xq * 4, y = tile_y0 + row;
+    if (y >= p.height || x >= p.width) continue;
+    const float4 Y = *(const float4 *)(lds + row * (YW * 4) + xq * 16);
+    float cb[4], cr[4];
+    // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
+    const int coff = (row / VS) * (CW * 4);
+    if (HS == 1) {
+      const float4 a = *(const float4 *)(lds + CB_OFF + coff + xq * 16);
+      const float4 b = *(const float4 *)(lds + CR_OFF + coff + xq * 16);
+      cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
+      cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
+    } else {
+      const float2 a = *(const float2 *)(lds + CB_OFF + coff + xq * 8);
+      const float2 b = *(const float2 *)(lds + CR_OFF + coff + xq * 8);
+      cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
+      cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
+    }
+    const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+    float r[4], g[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+      g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+      b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+    }
+    uint8_t *o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+    if (p.fast_store && x + 4 <= p.width) {
+      uint32_t w0 = 0, w1 = 0, w2 = 0;
+      w0 = pack_u8(r[0], 0, w0); w0 = pack_u8(g[0], 1, w0); w0 = pack_u8(b[0], 2, w0); w0 = pack_u8(r[1], 3, w0);
+      w1 = pack_u8(g[1], 0, w1); w1 = pack_u8(b[1], 1, w1); w1 = pack_u8(r[2], 2, w1); w1 = pack_u8(g[2], 3, w1);
+      w2 = pack_u8(b[2], 0, w2); w2 = pack_u8(r[3], 1, w2); w2 = pack_u8(g[3], 2, w2); w2 = pack_u8(b[3], 3, w2);
+      *(dw3_t *)o = dw3_t{w0, w1, w2};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (x + i < p.width) {
+          o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
+          o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
+          o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int HS, int VS>
+static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
+  hipLaunchKernelGGL((jb_tile_kernel<HS, VS>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
+  return hipGetLastError();
+}
+
+int jbk_mcus_per_tile(int hs, int vs) { return kTileBlocks / (hs * vs + 2); }
+
+hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
+  if (p.n_tiles <= 0) return hipSuccess;
+  if (hs == 1 && vs == 1) return launch_t<1, 1>(p, stream);
+  if (hs == 2 && vs == 1) return launch_t<2, 1>(p, stream);
+  if (hs == 1 && vs == 2) return launch_t<1, 2>(p, stream);
+  if (hs == 2 && vs == 2) return launch_t<2, 2>(p, stream);
+  return hipErrorInvalidValue;
+}
+
+const char *jbk_kernel_name(int hs, int vs) {
+  if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1>";
+  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1>";
+  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2>";
+  return "jb_tile_kernel<2, 2>";
+}

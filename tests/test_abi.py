@@ -1,0 +1,131 @@
+"""CPU tests of the C-ABI library (no compute calls: this container has no GPU): it loads, it
+exports every symbol include/jpegblk.h declares, its pure-host entry points (geometry, table
+resolution, the JFIF/Huffman front end, PPM sink) are correct, and the compute entry points
+fail loudly -- there is no CPU fallback behind the ABI."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import BASELINE_IMAGES, GOLD, ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def jb():
+    import jpeg_decoder_amd as jb
+    if not os.path.exists(jb.lib_path()):
+        jb.build_library()
+    return jb
+
+
+def test_library_exports_every_declared_symbol(jb):
+    header = open(os.path.join(ROOT, "include", "jpegblk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(jb_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 20
+    L = ctypes.CDLL(jb.lib_path())
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert L.jb_abi_version() == 1
+
+
+def test_no_cpu_fallback(jb):
+    """Without a HIP device the product refuses to compute (and says why)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(jb.JbError) as e:
+        jb.Context(0, 1 << 20, 1 << 20, 2)
+    assert e.value.status == -6 and "device" in str(e.value).lower()
+    # and the product never links, loads or imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "jpeg_decoder_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in text and "pyoracle" not in text and "jbo_" not in text, f
+
+
+def test_geometry_matches_oracle(jb, oracle):
+    from oracle.pyoracle import make_desc as odesc
+    for hs in (1, 2):
+        for vs in (1, 2):
+            for (w, h) in [(1, 1), (8, 8), (9, 17), (679, 451), (1279, 885), (4096, 4096), (65535, 65535)]:
+                a = jb.geometry_of(jb.make_desc(w, h, hs, vs))
+                b = oracle.geometry(odesc(w, h, hs, vs))
+                for f, _ in a._fields_:
+                    assert getattr(a, f) == getattr(b, f), (f, w, h, hs, vs)
+    for bad, status in [(jb.make_desc(0, 1, 1, 1), -2), (jb.make_desc(1, 65536, 1, 1), -2),
+                        (jb.make_desc(8, 8, 4, 1), -3), (jb.make_desc(8, 8, 1, 1, (4, 0, 0)), -4)]:
+        with pytest.raises(jb.JbError) as e:
+            jb.geometry_of(bad)
+        assert e.value.status == status
+
+
+def test_resolve_qtabs(jb):
+    q = np.arange(256, dtype=np.uint16).reshape(4, 64)
+    out = jb.resolve_qtabs(jb.make_desc(8, 8, 1, 1, (2, 0, 3)), q)
+    assert out.dtype == np.int32 and np.array_equal(out, q[[2, 0, 3]].astype(np.int32))
+
+
+@pytest.mark.parametrize("name", BASELINE_IMAGES)
+def test_front_end_matches_reference_coefficients(jb, manifest, name):
+    """Host marker parser + Huffman decoder == the reference's decodeHuffman() output
+    (golden coefficient dumps from the reference build), quant tables and frame geometry."""
+    desc, coef, qtabs, _ = load_golden(name)
+    data = open(os.path.join(GOLD, "images", name + ".jpg"), "rb").read()
+    d2, q2, c2 = jb.entropy_decode(data)
+    assert (d2.width, d2.height, d2.hs, d2.vs, list(d2.qtab_id)) == (desc.width, desc.height, desc.hs, desc.vs, list(desc.qtab_id))
+    assert np.array_equal(q2, qtabs)
+    assert c2.shape == coef.shape and np.array_equal(c2, coef)
+    d3, q3, c3 = jb.entropy_decode(data, headers_only=True)
+    assert c3 is None and d3.width == desc.width and np.array_equal(q3, qtabs)
+
+
+def test_front_end_rejections(jb):
+    """What the reference rejects with exit(1) (jpeg.cpp:69-87, 800-805) comes back as a status."""
+    prog = open(os.path.join(GOLD, "images", "prograssive-sample-2.jpg"), "rb").read()
+    good = open(os.path.join(GOLD, "images", "img2.jpg"), "rb").read()
+    cases = [(prog, -9), (b"not a jpeg at all", -8), (b"", -8), (good[:200], -8), (good[:-2000], -8)]
+    # a 1-component frame: patch Nf in the SOF0 header
+    sof = good.index(b"\xff\xc0")
+    gray = bytearray(good)
+    gray[sof + 9] = 1
+    cases.append((bytes(gray), -9))
+    # chroma sampled 2x1
+    bad = bytearray(good)
+    bad[sof + 10 + 3 + 1] = 0x21
+    cases.append((bytes(bad), -3))
+    for data, status in cases:
+        with pytest.raises(jb.JbError) as e:
+            jb.entropy_decode(data)
+        assert e.value.status == status, (status, str(e.value))
+
+
+def test_front_end_capacity_and_corruption(jb):
+    good = open(os.path.join(GOLD, "images", "img4.jpg"), "rb").read()
+    buf = np.frombuffer(good, np.uint8)
+    desc = jb.ImageDesc()
+    q = np.zeros((4, 64), np.uint16)
+    small = np.zeros(64, np.int16)
+    rc = jb.lib().jb_entropy_decode(buf.ctypes.data, buf.size, ctypes.byref(desc), q.ctypes.data, small.ctypes.data, small.nbytes)
+    assert rc == -5
+    # flip bytes in the middle of the scan: must return (corrupt or merely different), never crash
+    sos = good.index(b"\xff\xda")
+    for k in range(20):
+        dmg = bytearray(good)
+        pos = sos + 20 + 997 * k
+        dmg[pos] ^= 0x5A
+        try:
+            jb.entropy_decode(bytes(dmg))
+        except jb.JbError as e:
+            assert e.status == -8
+
+
+def test_write_ppm(jb, tmp_path):
+    rgb = np.arange(5 * 3 * 3, dtype=np.uint8).reshape(3, 15)
+    p = tmp_path / "o.ppm"
+    assert jb.lib().jb_write_ppm(str(p).encode(), rgb.ctypes.data, 5, 3, 15) == 0
+    raw = p.read_bytes()
+    assert raw.startswith(b"P6\n5 3\n255\n") and raw[len(b"P6\n5 3\n255\n"):] == rgb.tobytes()

@@ -1,0 +1,230 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libjpegblk.so), against
+the oracle and the committed golden vectors.  Parity bar: BIT-EXACT (integer/byte outputs);
+the +-1 LSB allowance of BASELINE.json is not used."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import BASELINE_IMAGES, GOLD, load_golden, load_kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jb():
+    import jpeg_decoder_amd as jb
+    assert jb.lib().jb_device_count() >= 1, jb.lib().jb_last_error(None)
+    return jb
+
+
+@pytest.fixture(scope="module")
+def big_ctx(jb):
+    # big enough for every host-buffer case in this file (1279x885 4:2:0 is the largest golden)
+    ctx = jb.Context(0, 64 << 20, 64 << 20, 3)
+    yield ctx
+    ctx.close()
+
+
+def _same_desc(jb, d):
+    return jb.make_desc(d.width, d.height, d.hs, d.vs, list(d.qtab_id))
+
+
+@pytest.mark.parametrize("name", BASELINE_IMAGES)
+def test_golden_images_host_api(jb, big_ctx, manifest, name):
+    desc, coef, qtabs, rgb = load_golden(name)
+    got = big_ctx.blocks_to_rgb(_same_desc(jb, desc), coef, qtabs)
+    assert np.array_equal(got, rgb)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == manifest["images"][name]["rgb_sha256"]
+
+
+def test_golden_kat_vectors(jb, big_ctx):
+    for name, (desc, coef, qtabs, rgb) in load_kat().items():
+        got = big_ctx.blocks_to_rgb(_same_desc(jb, desc), coef, qtabs)
+        assert np.array_equal(got, rgb), name
+
+
+@pytest.mark.parametrize("name", BASELINE_IMAGES)
+def test_decode_file_matches_reference(jb, big_ctx, name):
+    """decode(path) -> RGB: host front end + device block pipeline == the reference's output."""
+    _, _, _, rgb = load_golden(name)
+    got = big_ctx.decode_file(os.path.join(GOLD, "images", name + ".jpg"))
+    assert np.array_equal(got, rgb)
+
+
+def test_decode_file_rejects_progressive(jb, big_ctx):
+    with pytest.raises(jb.JbError) as e:
+        big_ctx.decode_file(os.path.join(GOLD, "images", "prograssive-sample-2.jpg"))
+    assert e.value.status == -9
+
+
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_random_blocks_vs_oracle_ragged_sizes(jb, big_ctx, oracle, hs, vs):
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    q = synth.annex_k_qtabs(50)
+    q[2] = 255
+    q[3] = np.arange(64, 0, -1)
+    sizes = [(1, 1), (8, 8), (9, 7), (100, 52), (511, 17), (513, 33), (1030, 19), (1537, 40), (777, 555)]
+    for i, (w, h) in enumerate(sizes):
+        for qid in [(0, 1, 2), (3, 3, 0)]:
+            n = oracle.geometry(odesc(w, h, hs, vs, qid)).n_coded_blocks
+            coef = synth.random_blocks(n, 100 + i) if i % 2 else synth.random_blocks(n, 200 + i, -700, 700)
+            got = big_ctx.blocks_to_rgb(jb.make_desc(w, h, hs, vs, qid), coef, q)
+            want = oracle.blocks_to_rgb(odesc(w, h, hs, vs, qid), coef, q, nthreads=4)
+            assert np.array_equal(got, want), (w, h, hs, vs, qid)
+
+
+def test_row_stride_and_untouched_padding(jb, big_ctx, oracle):
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    w, h = 301, 77
+    coef, q = synth.synth_blocks(w, h, 2, 2, 5)
+    stride = 3 * w + 29
+    out = np.full((h, stride), 0xAB, np.uint8)
+    t = big_ctx.submit(jb.make_desc(w, h, 2, 2), coef, q, out, stride)
+    big_ctx.wait(t)
+    want = oracle.blocks_to_rgb(odesc(w, h, 2, 2), coef, q)
+    assert np.array_equal(out[:, :3 * w].reshape(h, w, 3), want)
+    assert (out[:, 3 * w:] == 0xAB).all()
+
+
+def test_async_ring_many_images(jb, oracle):
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    w, h = 640, 360
+    desc = jb.make_desc(w, h, 1, 1)
+    with jb.Context.for_image(desc, 0, n_slots=3) as ctx:
+        ins, outs, tickets = [], [], []
+        for i in range(10):
+            coef, q = synth.synth_blocks(w, h, 1, 1, i)
+            out = np.zeros((h, 3 * w), np.uint8)
+            ins.append((coef, q))
+            outs.append(out)
+            tickets.append(ctx.submit(desc, coef, q, out))
+        # only the last n_slots tickets are still waitable; earlier ones completed when their
+        # slot was recycled
+        for t in tickets[-3:]:
+            ctx.wait(t)
+        with pytest.raises(jb.JbError) as e:
+            ctx.wait(tickets[0])
+        assert e.value.status == -7
+        for (coef, q), out in zip(ins, outs):
+            assert np.array_equal(out.reshape(h, w, 3), oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q))
+
+
+def test_device_batch_api_per_image_tables(jb, oracle):
+    """The device-resident entry point bench.py uses: a batch in one launch, torch tensors as
+    plumbing, per-image quantisation tables."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    w, h, hs, vs, nimg = 1000, 200, 2, 2, 5
+    desc = jb.make_desc(w, h, hs, vs, (0, 1, 2))
+    g = jb.geometry_of(desc)
+    coefs, q3s, qs = [], [], []
+    for i in range(nimg):
+        q = synth.annex_k_qtabs(40 + 10 * i)
+        q[2] = q[1][::-1]
+        coef, _ = synth.synth_blocks(w, h, hs, vs, i, qtabs=q, qtab_id=(0, 1, 2))
+        coefs.append(coef)
+        qs.append(q)
+        q3s.append(jb.resolve_qtabs(desc, q))
+    dev = torch.device("cuda:0")
+    coef_t = torch.from_numpy(np.stack(coefs)).to(dev)
+    q_t = torch.from_numpy(np.stack(q3s)).to(dev)
+    stride = 3 * w + 4
+    rgb_t = torch.zeros((nimg, h, stride), dtype=torch.uint8, device=dev)
+    with jb.Context(0) as ctx:
+        b = torch_batch(desc, nimg, coef_t, q_t, rgb_t, shared_qtabs=False)
+        ctx.blocks_to_rgb_device(b, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    got = rgb_t.cpu().numpy()
+    for i in range(nimg):
+        want = oracle.blocks_to_rgb(odesc(w, h, hs, vs, (0, 1, 2)), coefs[i], qs[i], nthreads=4)
+        assert np.array_equal(got[i, :, :3 * w].reshape(h, w, 3), want), i
+    assert (got[:, :, 3 * w:] == 0).all()
+    assert g.n_coded_blocks == coefs[0].shape[0]
+
+
+def test_unaligned_output_slow_path(jb, oracle):
+    """rgb pointer / stride not multiples of 4 -> the byte-store path of the kernel."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    w, h = 333, 41
+    desc = jb.make_desc(w, h, 1, 1)
+    coef, q = synth.synth_blocks(w, h, 1, 1, 9)
+    dev = torch.device("cuda:0")
+    coef_t = torch.from_numpy(coef).to(dev)
+    q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+    stride = 3 * w + 2
+    raw = torch.zeros(h * stride + 8, dtype=torch.uint8, device=dev)
+    view = raw[1:1 + h * stride].view(1, h, stride)
+    with jb.Context(0) as ctx:
+        b = torch_batch(desc, 1, coef_t.view(1, -1, 64), q_t, view)
+        ctx.blocks_to_rgb_device(b, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    got = view.cpu().numpy()[0, :, :3 * w].reshape(h, w, 3)
+    assert np.array_equal(got, oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q))
+
+
+@pytest.mark.parametrize("w,h,hs,vs", [(4096, 4096, 1, 1), (4096, 4096, 2, 2), (1920, 1080, 1, 1)])
+def test_full_size_configs_vs_oracle_and_properties(jb, oracle, w, h, hs, vs):
+    """BASELINE.json's single-GPU configurations at full size: bit-exact against the
+    (multi-threaded) oracle, plus two size-independent properties of the path:
+    MCU-permutation equivariance (blocks are independent) and idempotence of a
+    repeated launch."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    desc = jb.make_desc(w, h, hs, vs)
+    g = jb.geometry_of(desc)
+    coef, q = synth.synth_blocks(w, h, hs, vs, 1)
+    dev = torch.device("cuda:0")
+    coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
+    q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+    rgb_t = torch.zeros((1, h, 3 * w), dtype=torch.uint8, device=dev)
+    with jb.Context(0) as ctx:
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.blocks_to_rgb_device(torch_batch(desc, 1, coef_t, q_t, rgb_t), s)
+        torch.cuda.synchronize()
+        got = rgb_t.cpu().numpy()[0].reshape(h, w, 3)
+        want = oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=16)
+        assert np.array_equal(got, want)
+        # idempotence: same launch again into the same buffer
+        ctx.blocks_to_rgb_device(torch_batch(desc, 1, coef_t, q_t, rgb_t), s)
+        torch.cuda.synchronize()
+        assert np.array_equal(rgb_t.cpu().numpy()[0].reshape(h, w, 3), got)
+        # equivariance: reverse the MCU order -> the image is the MCU-wise mirror
+        bpm = g.blocks_per_mcu
+        mc = coef_t.view(g.mcus_y, g.mcus_x, bpm, 64)
+        flipped = torch.flip(mc, dims=(0, 1)).contiguous().view(1, -1, 64)
+        rgb2 = torch.zeros_like(rgb_t)
+        ctx.blocks_to_rgb_device(torch_batch(desc, 1, flipped, q_t, rgb2), s)
+        torch.cuda.synchronize()
+        mw, mh = 8 * hs, 8 * vs
+        a = rgb_t.view(g.mcus_y, mh, g.mcus_x, mw, 3)
+        b = torch.flip(rgb2.view(g.mcus_y, mh, g.mcus_x, mw, 3), dims=(0, 2))
+        assert torch.equal(a, b)
+
+
+def test_error_codes_no_exit(jb):
+    """Every reference exit(1) path on this seam is a returned status here."""
+    with jb.Context(0, 1 << 20, 1 << 20, 1) as ctx:
+        coef = np.zeros((4, 64), np.int16)
+        q = np.ones((4, 64), np.uint16)
+        for desc, status in [(jb.make_desc(8, 8, 3, 1), -3), (jb.make_desc(8, 8, 1, 1, (0, 5, 1)), -4),
+                             (jb.make_desc(0, 8, 1, 1), -2), (jb.make_desc(4096, 4096, 1, 1), -5)]:
+            with pytest.raises(jb.JbError) as e:
+                ctx.blocks_to_rgb(desc, coef, q)
+            assert e.value.status == status
+        assert jb.lib().jb_blocks_to_rgb(ctx._h, None, None, None, None, 0) == -1
+    with pytest.raises(jb.JbError) as e:
+        jb.Context(99)
+    assert e.value.status == -6
