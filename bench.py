@@ -98,6 +98,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
+    # all device work of this benchmark runs on one explicit torch stream, and the kernel is
+    # launched on that same stream through the C ABI, so torch.cuda.Event times the kernel
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     nimg = args.images_per_step
     desc = jb.make_desc(WIDTH, HEIGHT, HS, VS)
     g = jb.geometry_of(desc)
@@ -113,7 +117,6 @@ def main():
     rgb_t = torch.zeros((nimg, HEIGHT, 3 * WIDTH), dtype=torch.uint8, device=dev)
     batch = torch_batch(desc, nimg, coef_t, q_t, rgb_t)
     ctx = jb.Context(local_rank)
-    stream = torch.cuda.current_stream()
 
     def step():
         ctx.blocks_to_rgb_device(batch, stream.cuda_stream)

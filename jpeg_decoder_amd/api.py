@@ -65,6 +65,13 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the block pipeline)")
+    # PyTorch bundles its own HIP/HSA runtime with the same sonames as /opt/rocm's; two copies
+    # in one process cannot both open the GPU.  Load torch's first (when torch is present) so
+    # that libjpegblk.so binds to the runtime torch tensors and streams live in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(_LIB_PATH)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     pd = ctypes.POINTER(ImageDesc)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (profiles/run_profile.sh) into profiles/<tag>_summary.json:
+per-kernel average duration from the kernel trace, and HBM bytes per launch of the dominant
+kernel from the FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md (HBM section)
+prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports exactly half of the bytes of
+a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for wide stores."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(pattern):
+    for f in glob.glob(pattern, recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+def main():
+    out_dir, tag = sys.argv[1], sys.argv[2]
+    summary = {"tag": tag, "kernels": {}}
+    durs = {}
+    for r in rows(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv")):
+        name = r.get("Kernel_Name", "")
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        durs.setdefault(name, []).append(d)
+    for name, d in durs.items():
+        summary["kernels"][name[:120]] = {"calls": len(d), "avg_us": round(sum(d) / len(d), 3),
+                                          "min_us": round(min(d), 3), "max_us": round(max(d), 3),
+                                          "total_us": round(sum(d), 1)}
+    dom = max(durs, key=lambda k: sum(durs[k])) if durs else None
+    summary["dominant_kernel"] = dom
+
+    def counter(sub, cname):
+        vals = []
+        for r in rows(os.path.join(out_dir, sub, "**", "*counter_collection.csv")):
+            if r.get("Counter_Name") == cname and (dom is None or r.get("Kernel_Name") == dom):
+                vals.append(float(r["Counter_Value"]))
+        return vals
+
+    f = counter("pmc_fetch", "FETCH_SIZE")
+    w = counter("pmc_write", "WRITE_SIZE")
+    if f:
+        summary["FETCH_SIZE_KiB_avg_raw"] = sum(f) / len(f)
+    if w:
+        summary["WRITE_SIZE_KiB_avg_raw"] = sum(w) / len(w)
+    if f and w:
+        rd = 2.0 * 1024.0 * sum(f) / len(f)   # gfx950: FETCH_SIZE = 1/2 of wide streaming reads
+        wr = 1024.0 * sum(w) / len(w)
+        summary["hbm_read_bytes_per_launch"] = rd
+        summary["hbm_write_bytes_per_launch"] = wr
+        summary["hbm_bytes_per_launch"] = rd + wr
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.json")
+    # on the GPU box profiles/ is part of the scratch copy: also drop it under gpurun_out/
+    with open(os.path.join(out_dir, f"{tag}_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    try:
+        with open(path, "w") as fh:
+            json.dump(summary, fh, indent=1)
+    except OSError:
+        pass
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -134,13 +134,14 @@ def test_device_batch_api_per_image_tables(jb, oracle):
         qs.append(q)
         q3s.append(jb.resolve_qtabs(desc, q))
     dev = torch.device("cuda:0")
-    coef_t = torch.from_numpy(np.stack(coefs)).to(dev)
-    q_t = torch.from_numpy(np.stack(q3s)).to(dev)
+    ts = torch.cuda.Stream(dev)  # an explicit stream: a NULL handle would mean the ctx's own stream
     stride = 3 * w + 4
-    rgb_t = torch.zeros((nimg, h, stride), dtype=torch.uint8, device=dev)
-    with jb.Context(0) as ctx:
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(np.stack(coefs)).to(dev)
+        q_t = torch.from_numpy(np.stack(q3s)).to(dev)
+        rgb_t = torch.zeros((nimg, h, stride), dtype=torch.uint8, device=dev)
         b = torch_batch(desc, nimg, coef_t, q_t, rgb_t, shared_qtabs=False)
-        ctx.blocks_to_rgb_device(b, torch.cuda.current_stream().cuda_stream)
+        ctx.blocks_to_rgb_device(b, ts.cuda_stream)
         torch.cuda.synchronize()
     got = rgb_t.cpu().numpy()
     for i in range(nimg):
@@ -160,14 +161,15 @@ def test_unaligned_output_slow_path(jb, oracle):
     desc = jb.make_desc(w, h, 1, 1)
     coef, q = synth.synth_blocks(w, h, 1, 1, 9)
     dev = torch.device("cuda:0")
-    coef_t = torch.from_numpy(coef).to(dev)
-    q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+    ts = torch.cuda.Stream(dev)
     stride = 3 * w + 2
-    raw = torch.zeros(h * stride + 8, dtype=torch.uint8, device=dev)
-    view = raw[1:1 + h * stride].view(1, h, stride)
-    with jb.Context(0) as ctx:
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(coef).to(dev)
+        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+        raw = torch.zeros(h * stride + 8, dtype=torch.uint8, device=dev)
+        view = raw[1:1 + h * stride].view(1, h, stride)
         b = torch_batch(desc, 1, coef_t.view(1, -1, 64), q_t, view)
-        ctx.blocks_to_rgb_device(b, torch.cuda.current_stream().cuda_stream)
+        ctx.blocks_to_rgb_device(b, ts.cuda_stream)
         torch.cuda.synchronize()
     got = view.cpu().numpy()[0, :, :3 * w].reshape(h, w, 3)
     assert np.array_equal(got, oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q))
@@ -187,11 +189,12 @@ def test_full_size_configs_vs_oracle_and_properties(jb, oracle, w, h, hs, vs):
     g = jb.geometry_of(desc)
     coef, q = synth.synth_blocks(w, h, hs, vs, 1)
     dev = torch.device("cuda:0")
-    coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
-    q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
-    rgb_t = torch.zeros((1, h, 3 * w), dtype=torch.uint8, device=dev)
-    with jb.Context(0) as ctx:
-        s = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream(dev)
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
+        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+        rgb_t = torch.zeros((1, h, 3 * w), dtype=torch.uint8, device=dev)
+        s = ts.cuda_stream
         ctx.blocks_to_rgb_device(torch_batch(desc, 1, coef_t, q_t, rgb_t), s)
         torch.cuda.synchronize()
         got = rgb_t.cpu().numpy()[0].reshape(h, w, 3)
