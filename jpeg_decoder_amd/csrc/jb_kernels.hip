@@ -16,13 +16,17 @@
 //     linearly -- so that the 128-B-strided ds_read_b128 of stage 2 is bank-conflict free.
 //   * stage 2, one lane = one coded 8x8 block: 8 ds_read_b128 fetch the block, then dequantise
 //     and 16 1-D AAN passes run entirely in that lane's registers with static indexing (no
-//     cross-lane traffic, no redundant arithmetic).  The integer-valued result is written as
-//     f32 into planar image strips in LDS (Y strip 8*vs rows, Cb and Cr strips 8 rows; 48 KiB,
-//     overlaying the consumed coefficient bytes).
-//   * stage 3, one lane = 4 horizontally adjacent pixels: ds_read_b128 of Y, the (replicated)
-//     chroma samples, the colour transform, pack to 12 bytes and ONE global_store_dwordx3;
-//     consecutive lanes are consecutive in the image row, so a wave-instruction writes 768
-//     contiguous bytes (six whole 128-B lines).
+//     cross-lane traffic, no redundant arithmetic).  Lanes take blocks sorted by component, so
+//     the quantisation table is wave-uniform (SGPRs via scalar loads) wherever possible.
+//   * stage 3, twice (upper / lower half of the tile's pixel rows): the lanes write the
+//     integer-valued f32 samples of that half into planar strips in LDS (Y strip 4*vs rows, Cb and
+//     Cr strips 4 rows: 24 KiB, overlaying the consumed coefficient bytes; the other half waits
+//     in registers), then one lane = 4 horizontally adjacent pixels: ds_read_b128 of Y, the
+//     (replicated) chroma samples, the colour transform, pack to 12 bytes and ONE
+//     global_store_dwordx3; consecutive lanes are consecutive in the image row, so a
+//     wave-instruction writes 768 contiguous bytes (six whole 128-B lines).
+//     Halving the strips keeps a workgroup at 24.8 KiB of LDS = 6 workgroups (18 waves) per CU,
+//     which is what hides the HBM latency of stage 1 behind other workgroups' arithmetic.
 //
 // Arithmetic is bit-exact with the reference: int32 dequantise (v_mul_i32_i24), the AAN graph
 // of jpeg.cpp:598-662 evaluated in the same order with separate IEEE mul/add (this TU is built
@@ -38,6 +42,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((address_space(4))) int32_t q_const_t;  // scalar-loadable (constant) memory
 
 __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(float, bits); }
 
@@ -62,9 +67,16 @@ __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(f
 
 constexpr int kTileBlocks = 192;                  // coded blocks per tile = lanes per workgroup
 constexpr int kRawBytes = kTileBlocks * 128;      // 24 KiB of int16 coefficients
-constexpr int kPlaneBytes = kTileBlocks * 256;    // 48 KiB of f32 samples
-constexpr int kQtabOffset = kPlaneBytes;          // int32[3][64] after the planes
-constexpr int kLdsBytes = kPlaneBytes + 3 * 256;
+constexpr int kStripBytes = kTileBlocks * 128;    // 24 KiB: half of the tile's f32 samples
+constexpr int kLdsBytes = kRawBytes;
+static_assert(kStripBytes <= kRawBytes, "strips overlay the consumed coefficient bytes");
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for the
+// global stores of the previous colour phase (vmcnt(0)), putting HBM write latency on the
+// critical path between the two phases.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // One 1-D pass of the AAN network (reference jpeg.cpp:598-662 / 666-730), in place, each
 // output truncated toward zero exactly where the reference stores a float into an int.
@@ -142,14 +154,13 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   constexpr int MCUS = kTileBlocks / NB;        // MCUs per tile
   constexpr int YW = MCUS * 8 * HS;             // luma strip width in pixels
   constexpr int CW = MCUS * 8;                  // chroma strip width in samples
-  constexpr int YROWS = 8 * VS;
+  constexpr int YROWS = 4 * VS;                 // luma rows per phase (half of the tile's rows)
   constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
-  constexpr int CR_OFF = CB_OFF + 8 * CW * 4;
-  static_assert(CR_OFF + 8 * CW * 4 == kPlaneBytes, "strips must fill the plane area exactly");
+  constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
+  static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
 
   __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = tid >> 6;
 
   // ---- which tile (all wave-uniform) ----
@@ -176,18 +187,26 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(lds + (i * kTileBlocks + wave * 64) * 16),
                                      16, 0, 0);
   }
-  *(int32_t *)(lds + kQtabOffset + tid * 4) = qsrc[tid];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
 
   // ---- stage 2: this lane's block -> registers ----
-  const int n = tid;           // block index within the tile, decode order
-  const int mcu = n / NB;      // MCU within the tile
-  const int slot = n - mcu * NB;
-  const int comp = slot < NY ? 0 : slot - NY + 1;
+  // Lanes take the tile's blocks sorted by component (all Y, then Cb, then Cr) so that a wave
+  // holds at most two components: 4:4:4 -> one component per wave (its quantisation table is
+  // wave-uniform and lives in SGPRs), 4:2:0 -> waves 0,1 luma, wave 2 half Cb half Cr.
+  constexpr int NYT = NY * MCUS;  // luma blocks per tile
+  const int comp = tid < NYT ? 0 : (tid < NYT + MCUS ? 1 : 2);
+  const int mcu = comp == 0 ? tid / NY : tid - NYT - (comp - 1) * MCUS;  // MCU within the tile
+  const int slot = comp == 0 ? tid - mcu * NY : 0;                       // luma block within the MCU
+  const int n = mcu * NB + (comp == 0 ? slot : NY + comp - 1);           // block index, decode order
+  const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
+  const int comp_a = wbase < NYT ? 0 : (wbase < NYT + MCUS ? 1 : 2);           // first lane's component
+  const int comp_b = wbase + 63 < NYT ? 0 : (wbase + 63 < NYT + MCUS ? 1 : 2);  // last lane's component
+  const q_const_t *qa = (const q_const_t *)qsrc + comp_a * 64;
+  const q_const_t *qb = (const q_const_t *)qsrc + comp_b * 64;
   float v[64];
   {
-    uint32_t raw[32];
+    uint32_t raw[32];  // row k = dwords 4k..4k+3, two int16 (columns 2j, 2j+1) per dword
     const int f = (n >> 1) & 7;
     const char *base = lds + n * 128;
 #pragma unroll
@@ -198,22 +217,37 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       raw[j * 4 + 2] = t.z;
       raw[j * 4 + 3] = t.w;
     }
-    const int4 *q = (const int4 *)(lds + kQtabOffset + comp * 256);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_barrier();  // every lane holds its block: the coefficient bytes may be overwritten
+
+    // dequantise (jpeg.cpp:563-569): int32 product, int->float on first use (jpeg.cpp:598)
+    constexpr bool kUniformWaves = (NYT % 64 == 0) && (MCUS % 64 == 0);  // 4:4:4
+    if (kUniformWaves || comp_a == comp_b) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int4 qa = q[k * 2], qb = q[k * 2 + 1];
-      const int qq[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+      for (int k = 0; k < 8; k++) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const uint32_t w = raw[k * 4 + (i >> 1)];
-        const int c = (i & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
-        // reference jpeg.cpp:567: int32 product; int->float on first use (jpeg.cpp:598)
-        v[k * 8 + i] = (float)__mul24(c, qq[i]);
+        for (int i = 0; i < 8; i++) {
+          const uint32_t w = raw[k * 4 + (i >> 1)];
+          const int c = (i & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+          v[k * 8 + i] = (float)__mul24(c, qa[k * 8 + i]);
+        }
+      }
+    } else {
+      const bool second = comp == comp_b;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const uint32_t w = raw[k * 4 + (i >> 1)];
+          const int c = (i & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+          // both entries through scalar loads, then a per-lane select (v_cndmask)
+          const int q0 = __builtin_amdgcn_readfirstlane(qa[k * 8 + i]);
+          const int q1 = __builtin_amdgcn_readfirstlane(qb[k * 8 + i]);
+          v[k * 8 + i] = (float)__mul24(c, second ? q1 : q0);
+        }
       }
     }
   }
-  __syncthreads();  // every lane holds its block: the coefficient bytes may be overwritten
-
 #pragma unroll
   for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
     aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
@@ -223,75 +257,86 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
            v[k * 8 + 6], v[k * 8 + 7]);
 
-  {
-    // strip address of this block's row 0: luma block (bv,bh) of MCU m sits at rows 8*bv..,
-    // columns (m*HS + bh)*8..; chroma blocks at columns m*8..
-    int off, pitch;
-    if (comp == 0) {
-      const int bv = slot / HS, bh = slot - bv * HS;
-      pitch = YW * 4;
-      off = (bv * 8) * pitch + (mcu * HS + bh) * 32;
-    } else {
-      pitch = CW * 4;
-      off = (comp == 1 ? CB_OFF : CR_OFF) + mcu * 32;
-    }
-    char *dst = lds + off;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      *(float4 *)(dst + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-      *(float4 *)(dst + k * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
-    }
-  }
-  __syncthreads();
+  // ---- stage 3: two phases (upper / lower half of the tile's pixel rows) ----
+  // Where this lane's block lands in the strips.  VS == 1: every block contributes rows
+  // 4*phase..4*phase+3.  VS == 2: luma blocks of block-row bv contribute all 8 rows in phase
+  // bv; chroma blocks contribute rows 4*phase..4*phase+3 (chroma row r covers luma rows 2r, 2r+1).
+  const int bv = comp == 0 ? slot / HS : 0;
+  const int bh = comp == 0 ? slot - bv * HS : 0;
+  const int pitch = comp == 0 ? YW * 4 : CW * 4;
+  char *const dst = lds + (comp == 0 ? (mcu * HS + bh) * 32 : (comp == 1 ? CB_OFF : CR_OFF) + mcu * 32);
 
-  // ---- stage 3: colour transform + store, one lane = 4 adjacent pixels of one row ----
   constexpr int TASKS_PER_ROW = YW / 4;
   constexpr int TASKS = YROWS * TASKS_PER_ROW;
   const int tile_x0 = mx0 * 8 * HS;
-  const int tile_y0 = my * 8 * VS;
   uint8_t *img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
-  for (int t = tid; t < TASKS; t += kTileBlocks) {
-    const int row = t / TASKS_PER_ROW;
-    const int xq = t - row * TASKS_PER_ROW;
-    const int x = tile_x0 + xq * 4, y = tile_y0 + row;
-    if (y >= p.height || x >= p.width) continue;
-    const float4 Y = *(const float4 *)(lds + row * (YW * 4) + xq * 16);
-    float cb[4], cr[4];
-    // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
-    const int coff = (row / VS) * (CW * 4);
-    if (HS == 1) {
-      const float4 a = *(const float4 *)(lds + CB_OFF + coff + xq * 16);
-      const float4 b = *(const float4 *)(lds + CR_OFF + coff + xq * 16);
-      cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
-      cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
-    } else {
-      const float2 a = *(const float2 *)(lds + CB_OFF + coff + xq * 8);
-      const float2 b = *(const float2 *)(lds + CR_OFF + coff + xq * 8);
-      cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
-      cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
-    }
-    const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
-    float r[4], g[4], b[4];
+
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
-      g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
-      b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
-    }
-    uint8_t *o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
-    if (p.fast_store && x + 4 <= p.width) {
-      uint32_t w0 = 0, w1 = 0, w2 = 0;
-      w0 = pack_u8(r[0], 0, w0); w0 = pack_u8(g[0], 1, w0); w0 = pack_u8(b[0], 2, w0); w0 = pack_u8(r[1], 3, w0);
-      w1 = pack_u8(g[1], 0, w1); w1 = pack_u8(b[1], 1, w1); w1 = pack_u8(r[2], 2, w1); w1 = pack_u8(g[2], 3, w1);
-      w2 = pack_u8(b[2], 0, w2); w2 = pack_u8(r[3], 1, w2); w2 = pack_u8(g[3], 2, w2); w2 = pack_u8(b[3], 3, w2);
-      *(dw3_t *)o = dw3_t{w0, w1, w2};
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) lds_barrier();  // phase-0 colour reads are done: the strips may be rewritten
+    if (VS == 2 && comp == 0) {
+      if (bv == phase) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          *(float4 *)(dst + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+          *(float4 *)(dst + k * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+        }
+      }
     } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = phase * 4 + kk;
+        *(float4 *)(dst + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+        *(float4 *)(dst + kk * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+      }
+    }
+    lds_barrier();
+
+    // colour transform + store, one lane = 4 adjacent pixels of one row
+    const int y_base = my * 8 * VS + phase * YROWS;
+    for (int t = tid; t < TASKS; t += kTileBlocks) {
+      const int row = t / TASKS_PER_ROW;
+      const int xq = t - row * TASKS_PER_ROW;
+      const int x = tile_x0 + xq * 4, y = y_base + row;
+      if (y >= p.height || x >= p.width) continue;
+      const float4 Y = *(const float4 *)(lds + row * (YW * 4) + xq * 16);
+      float cb[4], cr[4];
+      // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
+      const int coff = (row / VS) * (CW * 4);
+      if (HS == 1) {
+        const float4 a = *(const float4 *)(lds + CB_OFF + coff + xq * 16);
+        const float4 b = *(const float4 *)(lds + CR_OFF + coff + xq * 16);
+        cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
+        cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
+      } else {
+        const float2 a = *(const float2 *)(lds + CB_OFF + coff + xq * 8);
+        const float2 b = *(const float2 *)(lds + CR_OFF + coff + xq * 8);
+        cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
+        cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
+      }
+      const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+      float r[4], g[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        if (x + i < p.width) {
-          o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
-          o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
-          o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
+        r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+        g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+        b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+      }
+      uint8_t *o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+      if (p.fast_store && x + 4 <= p.width) {
+        uint32_t w0 = 0, w1 = 0, w2 = 0;
+        w0 = pack_u8(r[0], 0, w0); w0 = pack_u8(g[0], 1, w0); w0 = pack_u8(b[0], 2, w0); w0 = pack_u8(r[1], 3, w0);
+        w1 = pack_u8(g[1], 0, w1); w1 = pack_u8(b[1], 1, w1); w1 = pack_u8(r[2], 2, w1); w1 = pack_u8(g[2], 3, w1);
+        w2 = pack_u8(b[2], 0, w2); w2 = pack_u8(r[3], 1, w2); w2 = pack_u8(g[3], 2, w2); w2 = pack_u8(b[3], 3, w2);
+        *(dw3_t *)o = dw3_t{w0, w1, w2};
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (x + i < p.width) {
+            o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
+            o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
+            o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
+          }
         }
       }
     }
