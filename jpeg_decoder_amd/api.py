@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libjpegblk.so")
+# JPEGBLK_LIB: experiment builds of the same ABI (tools/); the product is libjpegblk.so
+_LIB_PATH = os.environ.get("JPEGBLK_LIB") or os.path.join(_HERE, "libjpegblk.so")
 
 JB_OK = 0
 STATUS_NAMES = {0: "JB_OK", -1: "JB_ERR_NULL", -2: "JB_ERR_GEOMETRY", -3: "JB_ERR_SAMPLING",

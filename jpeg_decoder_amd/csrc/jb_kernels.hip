@@ -75,7 +75,11 @@ static_assert(kStripBytes <= kRawBytes, "strips overlay the consumed coefficient
 // global stores of the previous colour phase (vmcnt(0)), putting HBM write latency on the
 // critical path between the two phases.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef JB_EXPERIMENT_NO_BARRIER  // timing experiment only: results are wrong without barriers
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // One 1-D pass of the AAN network (reference jpeg.cpp:598-662 / 666-730), in place, each
@@ -134,34 +138,79 @@ __device__ __forceinline__ void aan_1d(float &x0, float &x1, float &x2, float &x
 }
 
 __device__ __forceinline__ uint32_t pack_u8(float x, uint32_t byte, uint32_t old) {
-  // reference jpeg.cpp:521-535: truncate to int, then clamp to 0..255; the value handed to the
-  // converter is already an integer in range, so its rounding mode is irrelevant
-  const float t = __builtin_amdgcn_fmed3f(__builtin_truncf(x), 0.0f, 255.0f);
-  return __builtin_amdgcn_cvt_pk_u8_f32(t, byte, old);
+  // reference jpeg.cpp:521-535: truncate toward zero, then clamp to 0..255.  v_cvt_pk_u8_f32
+  // saturates to 0..255 by itself but rounds to nearest (probed on gfx950, tools/probe_cvt.hip),
+  // so the truncation is explicit and the clamp is the instruction's own.
+  return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(x), byte, old);
 }
 
 struct __attribute__((packed, aligned(4))) dw3_t {
   uint32_t x, y, z;
 };
 
+// Timing experiments (tools/ builds only, never the product): a stage is skipped at run time
+// through a condition the compiler cannot fold, so the code and its registers stay.
+#ifdef JB_EXP_NO_LOAD
+#define JB_DO_LOAD(p) ((p).reserved == 777)
+#else
+#define JB_DO_LOAD(p) true
+#endif
+#ifdef JB_EXP_NO_IDCT
+#define JB_DO_IDCT(p) ((p).reserved == 777)
+#else
+#define JB_DO_IDCT(p) true
+#endif
+#ifdef JB_EXP_NO_COLOUR
+#define JB_DO_COLOUR(p) ((p).reserved == 777)
+#else
+#define JB_DO_COLOUR(p) true
+#endif
+#ifdef JB_EXP_NO_STORE
+#define JB_DO_STORE(p) ((p).reserved == 777)
+#else
+#define JB_DO_STORE(p) true
+#endif
+
 }  // namespace
+
+// Sorted-lane mapping: lanes take the tile's blocks sorted by component (all Y, then Cb, then
+// Cr) so that a wave holds at most two components.  4:4:4: wave w = component w (its
+// quantisation table is wave-uniform and lives in SGPRs); 4:2:0: waves 0,1 luma, wave 2 half Cb,
+// half Cr.  s = sorted index 0..191.
+template <int HS, int VS>
+struct LaneMap {
+  static constexpr int NY = HS * VS, NB = NY + 2, MCUS = kTileBlocks / NB, NYT = NY * MCUS;
+  __device__ static __forceinline__ int comp(int s) { return s < NYT ? 0 : (s < NYT + MCUS ? 1 : 2); }
+  __device__ static __forceinline__ int mcu(int s) {
+    const int c = comp(s);
+    return c == 0 ? s / NY : s - NYT - (c - 1) * MCUS;
+  }
+  __device__ static __forceinline__ int slot(int s) { return comp(s) == 0 ? s % NY : 0; }  // luma block in MCU
+  __device__ static __forceinline__ int block(int s) {                                      // decode order
+    const int c = comp(s);
+    return mcu(s) * NB + (c == 0 ? slot(s) : NY + c - 1);
+  }
+};
 
 // One workgroup (192 lanes) per tile.  See the file header for the three stages.
 template <int HS, int VS>
 __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
-  constexpr int NY = HS * VS;
-  constexpr int NB = NY + 2;
-  constexpr int MCUS = kTileBlocks / NB;        // MCUs per tile
+  using LM = LaneMap<HS, VS>;
+  constexpr int NB = LM::NB, MCUS = LM::MCUS, NYT = LM::NYT;
   constexpr int YW = MCUS * 8 * HS;             // luma strip width in pixels
   constexpr int CW = MCUS * 8;                  // chroma strip width in samples
   constexpr int YROWS = 4 * VS;                 // luma rows per phase (half of the tile's rows)
   constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
   constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
+  // 4:4:4: wave w owns component w, and its 8 KiB of coefficient bytes are exactly the 8 KiB its
+  // strip occupies, so loading and consuming the coefficients needs no workgroup barrier.
+  constexpr bool kWavePrivate = (NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192);
 
   __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
   const int tid = threadIdx.x;
-  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- which tile (all wave-uniform) ----
   const int tiles_per_image = p.tiles_per_row * p.mcus_y;
@@ -174,41 +223,38 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   const int last_block = nvalid * NB - 1;
   const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride +
                              ((int64_t)my * p.mcus_x + mx0) * (NB * 128);
-  const int32_t *qsrc = (const int32_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
+  const q_const_t *qsrc = (const q_const_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
 
-  // ---- stage 1: coefficients HBM -> LDS by LDS-DMA, swizzled; quant tables -> LDS ----
+  // ---- stage 1: coefficients HBM -> LDS by LDS-DMA.  Each wave fetches exactly the 64 blocks
+  // its own lanes will read: block of lane l at wave*8 KiB + l*128, 16-B chunk j at position
+  // j ^ ((l>>1)&7).  Every 8 lanes fetch one whole 128-B line. ----
+  char *const wave_lds = lds + wave * 8192;
+  if (JB_DO_LOAD(p))
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const int ci = i * kTileBlocks + tid;  // 16-B chunk index within the tile
-    const int n = ci >> 3;                 // block the chunk position belongs to
-    const int f = (n >> 1) & 7;
-    const int nsrc = min(n, last_block);   // lanes past a ragged tile re-read its last block
-    const uint8_t *src = tile_coef + nsrc * 128 + (((ci & 7) ^ f) << 4);
-    __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(lds + (i * kTileBlocks + wave * 64) * 16),
-                                     16, 0, 0);
+    const int l2 = i * 8 + (lane >> 3);  // the lane whose block this chunk belongs to
+    const int f = (l2 >> 1) & 7;
+    const int nsrc = min(LM::block(wave * 64 + l2), last_block);  // ragged tile: re-read its last block
+    const uint32_t off = (uint32_t)nsrc * 128u + (uint32_t)(((lane & 7) ^ f) << 4);
+    const uint8_t *src = tile_coef + off;
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(wave_lds + i * 1024), 16, 0, 0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
 
   // ---- stage 2: this lane's block -> registers ----
-  // Lanes take the tile's blocks sorted by component (all Y, then Cb, then Cr) so that a wave
-  // holds at most two components: 4:4:4 -> one component per wave (its quantisation table is
-  // wave-uniform and lives in SGPRs), 4:2:0 -> waves 0,1 luma, wave 2 half Cb half Cr.
-  constexpr int NYT = NY * MCUS;  // luma blocks per tile
-  const int comp = tid < NYT ? 0 : (tid < NYT + MCUS ? 1 : 2);
-  const int mcu = comp == 0 ? tid / NY : tid - NYT - (comp - 1) * MCUS;  // MCU within the tile
-  const int slot = comp == 0 ? tid - mcu * NY : 0;                       // luma block within the MCU
-  const int n = mcu * NB + (comp == 0 ? slot : NY + comp - 1);           // block index, decode order
-  const int wbase = __builtin_amdgcn_readfirstlane(wave) * 64;
-  const int comp_a = wbase < NYT ? 0 : (wbase < NYT + MCUS ? 1 : 2);           // first lane's component
-  const int comp_b = wbase + 63 < NYT ? 0 : (wbase + 63 < NYT + MCUS ? 1 : 2);  // last lane's component
-  const q_const_t *qa = (const q_const_t *)qsrc + comp_a * 64;
-  const q_const_t *qb = (const q_const_t *)qsrc + comp_b * 64;
+  const int comp = LM::comp(tid);
+  const int mcu = LM::mcu(tid);    // MCU within the tile
+  const int slot = LM::slot(tid);  // luma block within the MCU
+  const int comp_a = LM::comp(wave * 64);       // first lane's component (wave-uniform)
+  const int comp_b = LM::comp(wave * 64 + 63);  // last lane's component
+  const q_const_t *qa = qsrc + comp_a * 64;
+  const q_const_t *qb = qsrc + comp_b * 64;
   float v[64];
   {
     uint32_t raw[32];  // row k = dwords 4k..4k+3, two int16 (columns 2j, 2j+1) per dword
-    const int f = (n >> 1) & 7;
-    const char *base = lds + n * 128;
+    const int f = (lane >> 1) & 7;
+    const char *base = wave_lds + lane * 128;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!kWavePrivate) lds_barrier();
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const uint4 t = *(const uint4 *)(base + ((j ^ f) << 4));
@@ -218,11 +264,10 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       raw[j * 4 + 3] = t.w;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lds_barrier();  // every lane holds its block: the coefficient bytes may be overwritten
+    if (!kWavePrivate) lds_barrier();  // every lane holds its block: the bytes may be overwritten
 
     // dequantise (jpeg.cpp:563-569): int32 product, int->float on first use (jpeg.cpp:598)
-    constexpr bool kUniformWaves = (NYT % 64 == 0) && (MCUS % 64 == 0);  // 4:4:4
-    if (kUniformWaves || comp_a == comp_b) {
+    if (kWavePrivate || comp_a == comp_b) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
 #pragma unroll
@@ -248,6 +293,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       }
     }
   }
+  if (JB_DO_IDCT(p)) {
 #pragma unroll
   for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
     aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
@@ -256,20 +302,29 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
            v[k * 8 + 6], v[k * 8 + 7]);
+  }
 
   // ---- stage 3: two phases (upper / lower half of the tile's pixel rows) ----
   // Where this lane's block lands in the strips.  VS == 1: every block contributes rows
   // 4*phase..4*phase+3.  VS == 2: luma blocks of block-row bv contribute all 8 rows in phase
   // bv; chroma blocks contribute rows 4*phase..4*phase+3 (chroma row r covers luma rows 2r, 2r+1).
+  // A strip row is a sequence of 16-B chunks (4 samples); chunk c is stored at position
+  // c ^ ((c>>3)&1) so that the 8 lanes of a ds_write_b128 group hit 8 different bank quads.
   const int bv = comp == 0 ? slot / HS : 0;
   const int bh = comp == 0 ? slot - bv * HS : 0;
   const int pitch = comp == 0 ? YW * 4 : CW * 4;
-  char *const dst = lds + (comp == 0 ? (mcu * HS + bh) * 32 : (comp == 1 ? CB_OFF : CR_OFF) + mcu * 32);
+  const int blk_col = comp == 0 ? mcu * HS + bh : mcu;  // 8-sample column of the block in its strip
+  const int sw = (blk_col >> 2) & 1;
+  char *const dst = lds + (comp == 0 ? 0 : (comp == 1 ? CB_OFF : CR_OFF)) + blk_col * 32;
+  char *const dst_lo = dst + sw * 16;        // samples 0..3 of a row
+  char *const dst_hi = dst + (sw ^ 1) * 16;  // samples 4..7
 
   constexpr int TASKS_PER_ROW = YW / 4;
   constexpr int TASKS = YROWS * TASKS_PER_ROW;
+  static_assert(TASKS % 64 == 0, "whole wave-iterations");
+  constexpr bool kRowUniform = (TASKS_PER_ROW % 64 == 0);  // a wave-iteration stays within one row
   const int tile_x0 = mx0 * 8 * HS;
-  uint8_t *img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
 
 #pragma unroll
   for (int phase = 0; phase < 2; phase++) {
@@ -278,39 +333,50 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       if (bv == phase) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          *(float4 *)(dst + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-          *(float4 *)(dst + k * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+          *(float4 *)(dst_lo + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+          *(float4 *)(dst_hi + k * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
         }
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const int k = phase * 4 + kk;
-        *(float4 *)(dst + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-        *(float4 *)(dst + kk * pitch + 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
       }
     }
     lds_barrier();
 
-    // colour transform + store, one lane = 4 adjacent pixels of one row
+    // colour transform + store: one lane = 4 adjacent pixels of one row, one wave-iteration =
+    // 256 adjacent pixels (768 contiguous output bytes)
     const int y_base = my * 8 * VS + phase * YROWS;
-    for (int t = tid; t < TASKS; t += kTileBlocks) {
-      const int row = t / TASKS_PER_ROW;
-      const int xq = t - row * TASKS_PER_ROW;
+    for (int it = wave; it < TASKS / 64; it += kTileBlocks / 64) {
+      int row, xq;
+      if (kRowUniform) {
+        row = (it * 64) / TASKS_PER_ROW;  // scalar
+        xq = (it * 64) % TASKS_PER_ROW + lane;
+      } else {
+        const int t = it * 64 + lane;
+        row = t / TASKS_PER_ROW;
+        xq = t - row * TASKS_PER_ROW;
+      }
       const int x = tile_x0 + xq * 4, y = y_base + row;
       if (y >= p.height || x >= p.width) continue;
-      const float4 Y = *(const float4 *)(lds + row * (YW * 4) + xq * 16);
+      const int c = xq ^ ((xq >> 3) & 1);  // swizzled chunk position
+      const float4 Y = *(const float4 *)(lds + row * (YW * 4) + c * 16);
       float cb[4], cr[4];
       // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
       const int coff = (row / VS) * (CW * 4);
       if (HS == 1) {
-        const float4 a = *(const float4 *)(lds + CB_OFF + coff + xq * 16);
-        const float4 b = *(const float4 *)(lds + CR_OFF + coff + xq * 16);
+        const float4 a = *(const float4 *)(lds + CB_OFF + coff + c * 16);
+        const float4 b = *(const float4 *)(lds + CR_OFF + coff + c * 16);
         cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
         cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
       } else {
-        const float2 a = *(const float2 *)(lds + CB_OFF + coff + xq * 8);
-        const float2 b = *(const float2 *)(lds + CR_OFF + coff + xq * 8);
+        const int cc = xq >> 1;  // chroma chunk holding samples 2*xq, 2*xq+1
+        const int co = (cc ^ ((cc >> 3) & 1)) * 16 + (xq & 1) * 8;
+        const float2 a = *(const float2 *)(lds + CB_OFF + coff + co);
+        const float2 b = *(const float2 *)(lds + CR_OFF + coff + co);
         cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
         cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
       }
@@ -318,11 +384,17 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       float r[4], g[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
-        g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
-        b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+        if (JB_DO_COLOUR(p)) {
+          r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+          g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+          b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+        } else {
+          r[i] = yy[i], g[i] = cb[i], b[i] = cr[i];
+        }
       }
-      uint8_t *o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+      uint8_t *const rowp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)tile_x0 * 3;
+      uint8_t *const o = rowp + xq * 12;
+      if (!JB_DO_STORE(p)) continue;
       if (p.fast_store && x + 4 <= p.width) {
         uint32_t w0 = 0, w1 = 0, w2 = 0;
         w0 = pack_u8(r[0], 0, w0); w0 = pack_u8(g[0], 1, w0); w0 = pack_u8(b[0], 2, w0); w0 = pack_u8(r[1], 3, w0);
