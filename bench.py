@@ -72,8 +72,10 @@ def cpu_baseline(coef, qtabs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precondition", type=int, default=400,
+                    help="untimed launches before the warm-up steps (lets clocks/power settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--images-per-step", type=int, default=IMAGES_PER_STEP)
     args = ap.parse_args()
@@ -125,6 +127,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Pre-conditioning (untimed, before the W warm-up steps): MI355X power management needs a
+    # few hundred back-to-back launches of this kernel to settle (launch times go 240 -> 350 ->
+    # 240 us over the first ~100 launches, tools/steps.py); a stream workload runs in the settled
+    # state, so that is the state the K timed steps are taken in.
+    for _ in range(args.precondition):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -144,6 +144,35 @@ __device__ __forceinline__ uint32_t pack_u8(float x, uint32_t byte, uint32_t old
   return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(x), byte, old);
 }
 
+// 12 colour values (4 pixels x RGB, floats before truncation) -> 12 packed bytes.  The wave's
+// f32 rounding mode is switched to round-toward-zero around the twelve v_cvt_pk_u8_f32, which then
+// truncate AND saturate in one half-rate instruction each (bit-identical to truncate + clamp of
+// reference jpeg.cpp:521-535 on all inputs: probed on gfx950, tools/probe_cvt.hip); the mode is
+// back to round-to-nearest-even before any other float instruction of this wave can issue.
+__device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)[4], const float (&b)[4],
+                                           uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %1, %8, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %2, %13, 0, 0\n\t"
+      "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %9, 1, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %14, 1, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %10, 2, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %11, 2, %2\n\t"
+      "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+      "v_cvt_pk_u8_f32 %1, %7, 3, %1\n\t"
+      "v_cvt_pk_u8_f32 %2, %12, 3, %2\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+      // byte order: w0 = r0 g0 b0 r1 | w1 = g1 b1 r2 g2 | w2 = b2 r3 g3 b3
+      : "v"(r[0]), "v"(g[0]), "v"(b[0]), "v"(r[1]),   // %3..%6   -> w0 bytes 0..3
+        "v"(g[2]), "v"(g[1]), "v"(b[1]), "v"(r[2]),   // %7 (w1 byte 3), %8..%10 -> w1 bytes 0..2
+        "v"(g[3]), "v"(b[3]), "v"(b[2]), "v"(r[3]));  // %11 (w2 byte 2), %12 (w2 byte 3), %13, %14 -> w2 bytes 0,1
+}
+
 struct __attribute__((packed, aligned(4))) dw3_t {
   uint32_t x, y, z;
 };
@@ -396,10 +425,8 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
       uint8_t *const o = rowp + xq * 12;
       if (!JB_DO_STORE(p)) continue;
       if (p.fast_store && x + 4 <= p.width) {
-        uint32_t w0 = 0, w1 = 0, w2 = 0;
-        w0 = pack_u8(r[0], 0, w0); w0 = pack_u8(g[0], 1, w0); w0 = pack_u8(b[0], 2, w0); w0 = pack_u8(r[1], 3, w0);
-        w1 = pack_u8(g[1], 0, w1); w1 = pack_u8(b[1], 1, w1); w1 = pack_u8(r[2], 2, w1); w1 = pack_u8(g[2], 3, w1);
-        w2 = pack_u8(b[2], 0, w2); w2 = pack_u8(r[3], 1, w2); w2 = pack_u8(g[3], 2, w2); w2 = pack_u8(b[3], 3, w2);
+        uint32_t w0, w1, w2;
+        pack12_rtz(r, g, b, w0, w1, w2);
         *(dw3_t *)o = dw3_t{w0, w1, w2};
       } else {
 #pragma unroll

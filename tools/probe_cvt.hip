@@ -16,6 +16,21 @@ __global__ void cvt_probe(const float *in, uint32_t *direct, uint32_t *ref, int 
   ref[i] = __builtin_amdgcn_cvt_pk_u8_f32(t, 0, 0);
 }
 
+// v_cvt_pk_u8_f32 with the wave's f32 rounding mode switched to round-toward-zero around it
+__global__ void cvt_probe_rtz(const float *in, uint32_t *direct, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = in[i];
+  uint32_t r;
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=v"(r)
+      : "v"(x));
+  direct[i] = r;
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int MODE>
@@ -61,6 +76,13 @@ int main() {
   for (int i = 0; i < n; i++)
     if (a[i] != b[i]) { if (bad < 12) printf("  x=%.9g direct=%u trunc+clamp=%u\n", h[i], a[i], b[i]); bad++; }
   printf("cvt_pk_u8_f32(trunc(x)) probe: %d inputs, %d mismatches vs trunc+med3+cvt path\n", n, bad);
+
+  cvt_probe_rtz<<<(n + 255) / 256, 256>>>(d_in, d_a, n);
+  hipMemcpy(a.data(), d_a, n * 4, hipMemcpyDeviceToHost);
+  bad = 0;
+  for (int i = 0; i < n; i++)
+    if (a[i] != b[i]) { if (bad < 12) printf("  x=%.9g rtz-mode=%u trunc+clamp=%u\n", h[i], a[i], b[i]); bad++; }
+  printf("cvt_pk_u8_f32 under MODE.round=RTZ: %d inputs, %d mismatches vs trunc+med3+cvt path\n", n, bad);
 
   float *d_out; hipMalloc(&d_out, 1024 * 256 * 4 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
