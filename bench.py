@@ -150,16 +150,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     pixels_per_step = nimg * WIDTH * HEIGHT
+    from jpeg_decoder_amd.shard import job_throughput
+    total_pixels, elapsed = job_throughput(dist, dev, pixels_per_step * args.steps, elapsed)
+
     alg_bytes = nimg * (g.n_coded_blocks * 128 + WIDTH * HEIGHT * 3)  # 128 B/block in + 3 B/pixel out
     mean_ms = float(np.mean(kern_ms))
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-    value = n_gpus * pixels_per_step * args.steps / elapsed / 1e6
+    value = total_pixels / elapsed / 1e6
 
     if rank == 0:
         traffic = None

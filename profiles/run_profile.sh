@@ -9,8 +9,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+# the default bench command (400 untimed pre-conditioning launches, 20 warm-up, 200 timed steps)
+BENCH="python3 $R/bench.py --no-cpu-baseline"
+TIMED=200
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $BENCH > $OUT/pmc_write.log 2>&1 || echo "pmc write failed"
-cd $R && python3 profiles/summarize_profile.py $OUT $TAG
+cd $R && python3 profiles/summarize_profile.py $OUT $TAG $TIMED

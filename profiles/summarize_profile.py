@@ -20,9 +20,11 @@ def rows(pattern):
 
 def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
+    timed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     summary = {"tag": tag, "kernels": {}}
     durs = {}
-    for r in rows(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv")):
+    trace = sorted(rows(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+    for r in trace:
         name = r.get("Kernel_Name", "")
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         durs.setdefault(name, []).append(d)
@@ -32,6 +34,11 @@ def main():
                                           "total_us": round(sum(d), 1)}
     dom = max(durs, key=lambda k: sum(durs[k])) if durs else None
     summary["dominant_kernel"] = dom
+    if dom and timed and len(durs[dom]) >= timed:
+        # bench.py's timed region = the last `timed` launches (pre-conditioning and warm-up precede it)
+        last = durs[dom][-timed:]
+        summary["timed_region"] = {"launches": timed, "avg_us": round(sum(last) / timed, 3),
+                                   "min_us": round(min(last), 3), "max_us": round(max(last), 3)}
 
     def counter(sub, cname):
         vals = []
@@ -52,6 +59,14 @@ def main():
         summary["hbm_read_bytes_per_launch"] = rd
         summary["hbm_write_bytes_per_launch"] = wr
         summary["hbm_bytes_per_launch"] = rd + wr
+    if "hbm_bytes_per_launch" in summary:
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json"), "w") as fh:
+                json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"]}, fh)
+            with open(os.path.join(out_dir, "pmc_latest.json"), "w") as fh:
+                json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"]}, fh)
+        except OSError:
+            pass
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.json")
     # on the GPU box profiles/ is part of the scratch copy: also drop it under gpurun_out/
     with open(os.path.join(out_dir, f"{tag}_summary.json"), "w") as fh:
