@@ -78,7 +78,14 @@ def main():
                     help="untimed launches before the warm-up steps (lets clocks/power settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--images-per-step", type=int, default=IMAGES_PER_STEP)
+    ap.add_argument("--workload", default="4096x4096-444",
+                    help="WxH-444|420|422|440 (default = the headline workload; others are the "
+                         "remaining BASELINE.json configs, for DESIGN.md tables)")
     args = ap.parse_args()
+    global WIDTH, HEIGHT, HS, VS
+    dims, samp = args.workload.split("-")
+    WIDTH, HEIGHT = (int(v) for v in dims.split("x"))
+    HS, VS = {"444": (1, 1), "420": (2, 2), "422": (2, 1), "440": (1, 2)}[samp]
 
     import numpy as np
     import torch
@@ -172,9 +179,9 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"stream of {WIDTH}x{HEIGHT} baseline 4:4:4 images, {nimg} images per step "
+            "config": {"workload": f"stream of {WIDTH}x{HEIGHT} baseline {args.workload.split('-')[1]} images, {nimg} images per step "
                                    f"(one launch) per GPU, coefficient blocks resident in HBM",
-                       "images_per_step_per_gpu": nimg, "sampling": "4:4:4", "parallelism": f"images sharded x{n_gpus}, no collective"},
+                       "images_per_step_per_gpu": nimg, "sampling": {(1, 1): "4:4:4", (2, 2): "4:2:0", (2, 1): "4:2:2", (1, 2): "4:4:0"}[(HS, VS)], "parallelism": f"images sharded x{n_gpus}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": jb.lib().jb_kernel_name(desc).decode(), "algorithmic_bytes_per_launch": alg_bytes,

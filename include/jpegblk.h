@@ -163,6 +163,18 @@ int jb_decode_file(jb_ctx *ctx, const char *path, uint8_t **rgb, int32_t *width,
 int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t **rgb,
                      int32_t *width, int32_t *height);
 void jb_free(void *p);
+
+/* Batch of files: the multi-image form of decode(path) (BASELINE.json configs 4-5: "host Huffman
+ * on all cores overlapped with device IDCT").  `n_threads` host threads each own a context on
+ * `device_id` (own stream + pinned staging ring) and walk the files i = t, t + n_threads, ...:
+ * parse + Huffman-decode image i into pinned memory, submit it, and collect image i-1 while the
+ * device works -- so the entropy stage of one image overlaps the copies and the kernel of
+ * another, within a thread and across threads.  Per file: rgb[i] (malloc'd, tight rows; NULL on
+ * failure, release with jb_free), widths[i], heights[i], statuses[i] (a jb_status).  `times`
+ * (optional, 4 doubles) receives seconds: wall, summed entropy-decode, summed submit+wait,
+ * summed file read.  Returns JB_OK when every file decoded, else the first failing status. */
+int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
+                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses, double *times);
 /* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,

@@ -101,6 +101,9 @@ def lib():
     L.jb_entropy_decode.argtypes = [vp, ctypes.c_size_t, pd, vp, vp, ctypes.c_size_t]
     L.jb_decode_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.jb_decode_memory.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.jb_decode_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
@@ -226,6 +229,32 @@ class Context:
         finally:
             lib().jb_free(p)
         return arr.reshape(h.value, w.value, 3)
+
+
+def decode_batch(paths, n_threads=8, device=0, keep_pixels=True):
+    """jb_decode_batch: -> (list of uint8 [H,W,3] arrays or None, statuses, times dict)."""
+    n = len(paths)
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    rgb = (ctypes.c_void_p * n)()
+    w = (ctypes.c_int32 * n)()
+    h = (ctypes.c_int32 * n)()
+    st = (ctypes.c_int * n)()
+    times = (ctypes.c_double * 4)()
+    rc = lib().jb_decode_batch(device, arr, n, n_threads, rgb, w, h, st, times)
+    out = []
+    for i in range(n):
+        if rgb[i]:
+            if keep_pixels:
+                m = w[i] * h[i] * 3
+                a = np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).copy()
+                out.append(a.reshape(h[i], w[i], 3))
+            else:
+                out.append((w[i], h[i]))
+            lib().jb_free(rgb[i])
+        else:
+            out.append(None)
+    t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc}
+    return out, list(st), t
 
 
 def torch_batch(desc, n_images, coef_t, qtabs_t, rgb_t, rgb_row_stride=None, shared_qtabs=True):

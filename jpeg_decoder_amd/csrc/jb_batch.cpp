@@ -1,0 +1,183 @@
+// jb_batch.cpp -- multi-threaded decode(path) over a batch of files: host entropy decoding on
+// n_threads cores overlapped with the device block pipeline (include/jpegblk.h, jb_decode_batch).
+// The reference decodes one file per process, single-threaded (jpeg.cpp:916-929); images are
+// independent, so the batch parallelises by image with no shared state between threads.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/jpegblk.h"
+
+struct jb_ctx;
+int jb_fail_(jb_ctx *ctx, int code, const char *msg);
+
+namespace {
+
+double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+bool read_file(const char *path, std::vector<uint8_t> &buf) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n < 0) {
+    fclose(f);
+    return false;
+  }
+  buf.resize((size_t)n);
+  size_t got = n ? fread(buf.data(), 1, (size_t)n, f) : 0;
+  fclose(f);
+  return got == (size_t)n;
+}
+
+struct Parsed {
+  std::vector<uint8_t> bytes;
+  jb_image_desc desc;
+  jb_geometry geo;
+  uint16_t qtabs[256];
+  int status = JB_OK;
+};
+
+struct Totals {
+  std::mutex mu;
+  double t_entropy = 0, t_device = 0, t_read = 0;
+  int first_error = JB_OK;
+  std::string first_error_text;
+};
+
+void worker(int device_id, int t, int n_threads, const char *const *paths, int n_paths, uint8_t **rgb,
+            int32_t *widths, int32_t *heights, int *statuses, Totals *tot) {
+  double t_entropy = 0, t_device = 0, t_read = 0;
+  // pass 1: read + parse headers of this thread's files (sizes the context once)
+  std::vector<int> mine;
+  for (int i = t; i < n_paths; i += n_threads) mine.push_back(i);
+  std::vector<Parsed> parsed(mine.size());
+  size_t max_coef = 0, max_rgb = 0;
+  for (size_t k = 0; k < mine.size(); k++) {
+    Parsed &p = parsed[k];
+    double a = now_s();
+    if (!read_file(paths[mine[k]], p.bytes)) {
+      p.status = JB_ERR_FORMAT;
+      continue;
+    }
+    t_read += now_s() - a;
+    p.status = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, nullptr, 0);
+    if (p.status == JB_OK) p.status = jb_geometry_of(&p.desc, &p.geo);
+    if (p.status == JB_OK) {
+      if ((size_t)p.geo.coef_bytes > max_coef) max_coef = (size_t)p.geo.coef_bytes;
+      if ((size_t)p.geo.rgb_bytes > max_rgb) max_rgb = (size_t)p.geo.rgb_bytes;
+    }
+  }
+  jb_ctx *ctx = nullptr;
+  const int kSlots = 2;
+  int rc = max_coef ? jb_ctx_create(device_id, max_coef, max_rgb, kSlots, &ctx) : JB_OK;
+  int16_t *coef[kSlots] = {nullptr, nullptr};
+  if (rc == JB_OK && max_coef)
+    for (int s = 0; s < kSlots && rc == JB_OK; s++) {
+      coef[s] = (int16_t *)jb_pinned_alloc(max_coef);
+      if (!coef[s]) rc = JB_ERR_HIP;
+    }
+  // pass 2: decode image k into pinned slot k%2, submit, then wait for image k-1
+  int pending_ticket = -1, pending_k = -1;
+  auto finish = [&](int k, int st) {
+    const int i = mine[k];
+    statuses[i] = st;
+    if (st != JB_OK) {
+      jb_free(rgb[i]);
+      rgb[i] = nullptr;
+      std::lock_guard<std::mutex> g(tot->mu);
+      if (tot->first_error == JB_OK) {
+        tot->first_error = st;
+        tot->first_error_text = std::string(paths[i]) + ": " + jb_last_error(ctx);
+      }
+    }
+  };
+  for (size_t k = 0; k < mine.size(); k++) {
+    Parsed &p = parsed[k];
+    const int i = mine[k];
+    rgb[i] = nullptr;
+    widths[i] = heights[i] = 0;
+    int st = rc != JB_OK ? rc : p.status;
+    int ticket = -1;
+    if (st == JB_OK) {
+      double a = now_s();
+      st = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, coef[k % kSlots], max_coef);
+      t_entropy += now_s() - a;
+    }
+    if (st == JB_OK) {
+      rgb[i] = (uint8_t *)malloc((size_t)p.geo.rgb_bytes);
+      widths[i] = p.desc.width;
+      heights[i] = p.desc.height;
+      if (!rgb[i]) st = JB_ERR_CAPACITY;
+    }
+    if (st == JB_OK) {
+      double a = now_s();
+      st = jb_submit(ctx, &p.desc, coef[k % kSlots], p.qtabs, rgb[i], 3LL * p.desc.width, &ticket);
+      t_device += now_s() - a;
+    }
+    // the previous image: its pinned slot is needed again two images from now
+    if (pending_ticket >= 0) {
+      double a = now_s();
+      int wst = jb_wait(ctx, pending_ticket);
+      t_device += now_s() - a;
+      finish(pending_k, wst);
+      pending_ticket = -1;
+    }
+    if (st == JB_OK) {
+      pending_ticket = ticket;
+      pending_k = (int)k;
+    } else {
+      finish((int)k, st);
+    }
+    p.bytes.clear();
+    p.bytes.shrink_to_fit();
+  }
+  if (pending_ticket >= 0) {
+    double a = now_s();
+    int wst = jb_wait(ctx, pending_ticket);
+    t_device += now_s() - a;
+    finish(pending_k, wst);
+  }
+  for (int s = 0; s < kSlots; s++) jb_pinned_free(coef[s]);
+  jb_ctx_destroy(ctx);
+  std::lock_guard<std::mutex> g(tot->mu);
+  tot->t_entropy += t_entropy;
+  tot->t_device += t_device;
+  tot->t_read += t_read;
+}
+
+}  // namespace
+
+extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
+                               uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
+                               double *times) {
+  if (!paths || !rgb || !widths || !heights || !statuses)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_batch: NULL pointer");
+  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_decode_batch: negative count");
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
+  Totals tot;
+  const double t0 = now_s();
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back(worker, device_id, t, n_threads, paths, n_paths, rgb, widths, heights, statuses, &tot);
+  for (auto &x : th) x.join();
+  if (times) {
+    times[0] = now_s() - t0;
+    times[1] = tot.t_entropy;
+    times[2] = tot.t_device;
+    times[3] = tot.t_read;
+  }
+  if (tot.first_error != JB_OK) return jb_fail_(nullptr, tot.first_error, tot.first_error_text.c_str());
+  return JB_OK;
+}

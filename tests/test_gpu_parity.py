@@ -231,3 +231,27 @@ def test_error_codes_no_exit(jb):
     with pytest.raises(jb.JbError) as e:
         jb.Context(99)
     assert e.value.status == -6
+
+
+def test_decode_batch_threads_and_failures(jb, tmp_path):
+    """Multi-threaded decode(path) over a batch: host Huffman on several threads overlapped with
+    the device stage; a rejected file in the middle is reported per file, the rest decode."""
+    names = BASELINE_IMAGES * 3
+    paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
+    paths.insert(4, os.path.join(GOLD, "images", "prograssive-sample-2.jpg"))
+    paths.insert(9, str(tmp_path / "missing.jpg"))
+    imgs, statuses, times = jb.decode_batch(paths, n_threads=4)
+    assert times["rc"] == -9 or times["rc"] == -8
+    k = 0
+    for i, p in enumerate(paths):
+        if i == 4:
+            assert statuses[i] == -9 and imgs[i] is None
+        elif i == 9:
+            assert statuses[i] == -8 and imgs[i] is None
+        else:
+            _, _, _, rgb = load_golden(names[k])
+            assert statuses[i] == 0 and np.array_equal(imgs[i], rgb), p
+            k += 1
+    # single thread, clean batch
+    imgs, statuses, times = jb.decode_batch(paths[:4], n_threads=1)
+    assert times["rc"] == 0 and all(s == 0 for s in statuses)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""End-to-end regimes of SURVEY 8(d) beside the kernel-only number of bench.py:
+  (1) full decode(path): JPEG files -> host Huffman on T threads -> pinned H2D -> kernel -> D2H
+      (jb_decode_batch), on synthetic baseline JPEGs written with PIL (quality 90, no Huffman
+      optimisation -- the kind of file the reference's front end accepts);
+  (2) PCIe-inclusive block pipeline: pre-decoded coefficient blocks in pinned host memory ->
+      jb_submit/jb_wait ring -> pixels in pinned host memory (no Huffman).
+Usage: python tools/e2e_bench.py [--size 1920x1080] [--sub 444|420] [--n 256] [--threads 1,8,16,64]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jpeg_decoder_amd as jb  # noqa: E402
+
+
+def make_jpegs(n_distinct, w, h, sub, out_dir):
+    from PIL import Image
+    paths = []
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(n_distinct):
+        base = np.stack([(xx * (2 + i) + yy) % 256, (yy * 3 + xx * (1 + i)) % 256, (xx + yy * 2) // 3 % 256], -1)
+        noise = rng.normal(0, 12, (h // 8 + 1, w // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:h, :w]
+        img = np.clip(base * 0.6 + 60 + noise + rng.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
+        p = os.path.join(out_dir, f"synth_{w}x{h}_{sub}_{i}.jpg")
+        Image.fromarray(img).save(p, "JPEG", quality=90, subsampling={"444": 0, "420": 2}[sub], optimize=False)
+        paths.append(p)
+    return paths
+
+
+def pinned_array(nbytes, dtype):
+    p = jb.lib().jb_pinned_alloc(nbytes)
+    if not p:
+        raise MemoryError("jb_pinned_alloc")
+    a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)).view(dtype)
+    return p, a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--sub", default="444")
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--threads", default="1,8,16,32,64")
+    args = ap.parse_args()
+    w, h = (int(v) for v in args.size.split("x"))
+    out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count()}
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        distinct = make_jpegs(8, w, h, args.sub, d)
+        paths = [distinct[i % len(distinct)] for i in range(args.n)]
+        out["file_kbytes_mean"] = round(float(np.mean([os.path.getsize(p) for p in distinct])) / 1024, 1)
+        # warm-up (file cache, HIP init)
+        jb.decode_batch(paths[:8], n_threads=4, keep_pixels=False)
+        res = []
+        for t in [int(x) for x in args.threads.split(",")]:
+            _, st, tm = jb.decode_batch(paths, n_threads=t, keep_pixels=False)
+            assert all(s == 0 for s in st), st[:8]
+            res.append({"threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
+                        "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
+                        "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
+                        "wall_s": round(tm["wall_s"], 3)})
+        out["decode_path"] = res
+        # (2) PCIe-inclusive block pipeline from pre-decoded coefficients
+        desc, q, coef = jb.entropy_decode(open(distinct[0], "rb").read())
+        g = jb.geometry_of(desc)
+        slots = 3
+        bufs = []
+        for _ in range(slots):
+            pc, ac = pinned_array(g.coef_bytes, np.int16)
+            ac[:] = coef.reshape(-1)
+            pr, ar = pinned_array(g.rgb_bytes, np.uint8)
+            bufs.append((pc, ac, pr, ar))
+        with jb.Context(0, g.coef_bytes, g.rgb_bytes, slots) as ctx:
+            n = max(args.n, 64)
+            tickets = []
+            for warm in (True, False):
+                t0 = time.perf_counter()
+                for i in range(n):
+                    _, ac, _, ar = bufs[i % slots]
+                    tickets.append(ctx.submit(desc, ac, q, ar))
+                    if len(tickets) >= slots:
+                        ctx.wait(tickets.pop(0))
+                while tickets:
+                    ctx.wait(tickets.pop(0))
+                dt = time.perf_counter() - t0
+            out["pcie_pipeline"] = {"images_per_s": round(n / dt, 1), "mpix_per_s": round(n * w * h / dt / 1e6, 1),
+                                    "GBps_h2d_plus_d2h": round(n * (g.coef_bytes + g.rgb_bytes) / dt / 1e9, 2)}
+        for pc, _, pr, _ in bufs:
+            jb.lib().jb_pinned_free(pc)
+            jb.lib().jb_pinned_free(pr)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
