@@ -175,6 +175,15 @@ void jb_free(void *p);
  * summed file read.  Returns JB_OK when every file decoded, else the first failing status. */
 int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
                     uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses, double *times);
+/* The same with the per-thread contexts and pinned buffers kept across runs (creating them --
+ * page pinning above all -- costs milliseconds per thread).  max_*_bytes pre-size every thread's
+ * staging (0,0: sized lazily by the first run); a later run with larger images re-sizes. */
+typedef struct jb_batch_decoder jb_batch_decoder;
+int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes, size_t max_rgb_bytes,
+                            jb_batch_decoder **out);
+int jb_batch_decoder_run(jb_batch_decoder *dec, const char *const *paths, int n_paths, uint8_t **rgb,
+                         int32_t *widths, int32_t *heights, int *statuses, double *times);
+void jb_batch_decoder_destroy(jb_batch_decoder *dec);
 /* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,

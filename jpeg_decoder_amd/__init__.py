@@ -9,7 +9,7 @@ There is no CPU fallback: if the library is missing, or no HIP device is usable,
 loudly (ImportError / JbError).
 """
 from .api import (JbError, Context, ImageDesc, Geometry, DeviceBatch, lib, lib_path, make_desc,
-                  geometry_of, resolve_qtabs, entropy_decode, decode_batch, build_library)
+                  geometry_of, resolve_qtabs, entropy_decode, decode_batch, BatchDecoder, build_library)
 
 __all__ = ["JbError", "Context", "ImageDesc", "Geometry", "DeviceBatch", "lib", "lib_path",
-           "make_desc", "geometry_of", "resolve_qtabs", "entropy_decode", "decode_batch", "build_library"]
+           "make_desc", "geometry_of", "resolve_qtabs", "entropy_decode", "decode_batch", "BatchDecoder", "build_library"]

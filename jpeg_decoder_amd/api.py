@@ -104,6 +104,10 @@ def lib():
     L.jb_decode_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+    L.jb_batch_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
+    L.jb_batch_decoder_destroy.argtypes = [vp]
+    L.jb_batch_decoder_destroy.restype = None
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
@@ -231,7 +235,29 @@ class Context:
         return arr.reshape(h.value, w.value, 3)
 
 
-def decode_batch(paths, n_threads=8, device=0, keep_pixels=True):
+class BatchDecoder:
+    """jb_batch_decoder: n_threads host lanes (context + pinned buffers each), reusable."""
+
+    def __init__(self, n_threads=8, device=0, max_coef_bytes=0, max_rgb_bytes=0):
+        self._h = ctypes.c_void_p()
+        _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
+
+    def run(self, paths, keep_pixels=True):
+        return decode_batch(paths, keep_pixels=keep_pixels, _decoder=self._h)
+
+    def close(self):
+        if self._h:
+            lib().jb_batch_decoder_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None):
     """jb_decode_batch: -> (list of uint8 [H,W,3] arrays or None, statuses, times dict)."""
     n = len(paths)
     arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
@@ -240,7 +266,10 @@ def decode_batch(paths, n_threads=8, device=0, keep_pixels=True):
     h = (ctypes.c_int32 * n)()
     st = (ctypes.c_int * n)()
     times = (ctypes.c_double * 4)()
-    rc = lib().jb_decode_batch(device, arr, n, n_threads, rgb, w, h, st, times)
+    if _decoder is not None:
+        rc = lib().jb_batch_decoder_run(_decoder, arr, n, rgb, w, h, st, times)
+    else:
+        rc = lib().jb_decode_batch(device, arr, n, n_threads, rgb, w, h, st, times)
     out = []
     for i in range(n):
         if rgb[i]:

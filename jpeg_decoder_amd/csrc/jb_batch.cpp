@@ -54,7 +54,44 @@ struct Totals {
   std::string first_error_text;
 };
 
-void worker(int device_id, int t, int n_threads, const char *const *paths, int n_paths, uint8_t **rgb,
+constexpr int kSlots = 2;
+
+// what one worker thread owns across runs: a context (stream + device staging ring) and the
+// pinned coefficient buffers the Huffman stage decodes into
+struct Lane {
+  jb_ctx *ctx = nullptr;
+  int16_t *coef[kSlots] = {nullptr, nullptr};
+  size_t cap_coef = 0, cap_rgb = 0;
+  int device = 0;
+
+  int ensure(size_t need_coef, size_t need_rgb) {
+    if (ctx && need_coef <= cap_coef && need_rgb <= cap_rgb) return JB_OK;
+    release();
+    int rc = jb_ctx_create(device, need_coef, need_rgb, kSlots, &ctx);
+    for (int s = 0; s < kSlots && rc == JB_OK; s++) {
+      coef[s] = (int16_t *)jb_pinned_alloc(need_coef);
+      if (!coef[s]) rc = JB_ERR_HIP;
+    }
+    if (rc == JB_OK) {
+      cap_coef = need_coef;
+      cap_rgb = need_rgb;
+    } else {
+      release();
+    }
+    return rc;
+  }
+  void release() {
+    for (int s = 0; s < kSlots; s++) {
+      jb_pinned_free(coef[s]);
+      coef[s] = nullptr;
+    }
+    jb_ctx_destroy(ctx);
+    ctx = nullptr;
+    cap_coef = cap_rgb = 0;
+  }
+};
+
+void worker(Lane *lane, int t, int n_threads, const char *const *paths, int n_paths, uint8_t **rgb,
             int32_t *widths, int32_t *heights, int *statuses, Totals *tot) {
   double t_entropy = 0, t_device = 0, t_read = 0;
   // pass 1: read + parse headers of this thread's files (sizes the context once)
@@ -77,15 +114,10 @@ void worker(int device_id, int t, int n_threads, const char *const *paths, int n
       if ((size_t)p.geo.rgb_bytes > max_rgb) max_rgb = (size_t)p.geo.rgb_bytes;
     }
   }
-  jb_ctx *ctx = nullptr;
-  const int kSlots = 2;
-  int rc = max_coef ? jb_ctx_create(device_id, max_coef, max_rgb, kSlots, &ctx) : JB_OK;
-  int16_t *coef[kSlots] = {nullptr, nullptr};
-  if (rc == JB_OK && max_coef)
-    for (int s = 0; s < kSlots && rc == JB_OK; s++) {
-      coef[s] = (int16_t *)jb_pinned_alloc(max_coef);
-      if (!coef[s]) rc = JB_ERR_HIP;
-    }
+  int rc = max_coef ? lane->ensure(max_coef, max_rgb) : JB_OK;
+  jb_ctx *ctx = lane->ctx;
+  int16_t **coef = lane->coef;
+  max_coef = lane->cap_coef;
   // pass 2: decode image k into pinned slot k%2, submit, then wait for image k-1
   int pending_ticket = -1, pending_k = -1;
   auto finish = [&](int k, int st) {
@@ -147,8 +179,6 @@ void worker(int device_id, int t, int n_threads, const char *const *paths, int n
     t_device += now_s() - a;
     finish(pending_k, wst);
   }
-  for (int s = 0; s < kSlots; s++) jb_pinned_free(coef[s]);
-  jb_ctx_destroy(ctx);
   std::lock_guard<std::mutex> g(tot->mu);
   tot->t_entropy += t_entropy;
   tot->t_device += t_device;
@@ -157,20 +187,58 @@ void worker(int device_id, int t, int n_threads, const char *const *paths, int n
 
 }  // namespace
 
-extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
-                               uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
-                               double *times) {
-  if (!paths || !rgb || !widths || !heights || !statuses)
-    return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_batch: NULL pointer");
-  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_decode_batch: negative count");
+struct jb_batch_decoder {
+  int device = 0;
+  std::vector<Lane> lanes;
+};
+
+extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
+                                       size_t max_rgb_bytes, jb_batch_decoder **out) {
+  if (!out) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create: out is NULL");
+  *out = nullptr;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
+  jb_batch_decoder *d = new jb_batch_decoder();
+  d->device = device_id;
+  d->lanes.resize((size_t)n_threads);
+  for (auto &l : d->lanes) l.device = device_id;
+  if (max_coef_bytes && max_rgb_bytes) {
+    // create the per-thread contexts and pinned buffers in parallel (page pinning is slow)
+    std::vector<std::thread> th;
+    std::vector<int> rcs(d->lanes.size(), JB_OK);
+    for (size_t i = 0; i < d->lanes.size(); i++)
+      th.emplace_back([&, i] { rcs[i] = d->lanes[i].ensure(max_coef_bytes, max_rgb_bytes); });
+    for (auto &x : th) x.join();
+    for (int rc : rcs)
+      if (rc != JB_OK) {
+        for (auto &l : d->lanes) l.release();
+        delete d;
+        return jb_fail_(nullptr, rc, jb_last_error(nullptr));
+      }
+  }
+  *out = d;
+  return JB_OK;
+}
+
+extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
+  if (!d) return;
+  for (auto &l : d->lanes) l.release();
+  delete d;
+}
+
+extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *paths, int n_paths,
+                                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
+                                    double *times) {
+  if (!d || !paths || !rgb || !widths || !heights || !statuses)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_run: NULL pointer");
+  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
+  int n_threads = (int)d->lanes.size();
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   const double t0 = now_s();
   std::vector<std::thread> th;
   for (int t = 0; t < n_threads; t++)
-    th.emplace_back(worker, device_id, t, n_threads, paths, n_paths, rgb, widths, heights, statuses, &tot);
+    th.emplace_back(worker, &d->lanes[(size_t)t], t, n_threads, paths, n_paths, rgb, widths, heights, statuses, &tot);
   for (auto &x : th) x.join();
   if (times) {
     times[0] = now_s() - t0;
@@ -180,4 +248,18 @@ extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_pa
   }
   if (tot.first_error != JB_OK) return jb_fail_(nullptr, tot.first_error, tot.first_error_text.c_str());
   return JB_OK;
+}
+
+extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
+                               uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
+                               double *times) {
+  if (!paths || !rgb || !widths || !heights || !statuses)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_batch: NULL pointer");
+  if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
+  jb_batch_decoder *d = nullptr;
+  int rc = jb_batch_decoder_create(device_id, n_threads, 0, 0, &d);  // lanes size themselves
+  if (rc) return rc;
+  rc = jb_batch_decoder_run(d, paths, n_paths, rgb, widths, heights, statuses, times);
+  jb_batch_decoder_destroy(d);
+  return rc;
 }

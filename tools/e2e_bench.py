@@ -60,8 +60,12 @@ def main():
         # warm-up (file cache, HIP init)
         jb.decode_batch(paths[:8], n_threads=4, keep_pixels=False)
         res = []
+        d0, _, _ = jb.entropy_decode(open(distinct[0], "rb").read(), headers_only=True)
+        g0 = jb.geometry_of(d0)
         for t in [int(x) for x in args.threads.split(",")]:
-            _, st, tm = jb.decode_batch(paths, n_threads=t, keep_pixels=False)
+            with jb.BatchDecoder(t, 0, g0.coef_bytes, g0.rgb_bytes) as dec:
+                dec.run(paths[:t], keep_pixels=False)          # touch every lane once
+                _, st, tm = dec.run(paths, keep_pixels=False)  # timed: contexts and pinned buffers exist
             assert all(s == 0 for s in st), st[:8]
             res.append({"threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
                         "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
