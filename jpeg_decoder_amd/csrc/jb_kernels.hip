@@ -173,6 +173,8 @@ __device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)
         "v"(g[3]), "v"(b[3]), "v"(b[2]), "v"(r[3]));  // %11 (w2 byte 2), %12 (w2 byte 3), %13, %14 -> w2 bytes 0,1
 }
 
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+
 struct __attribute__((packed, aligned(4))) dw3_t {
   uint32_t x, y, z;
 };
@@ -354,6 +356,15 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   constexpr bool kRowUniform = (TASKS_PER_ROW % 64 == 0);  // a wave-iteration stays within one row
   const int tile_x0 = mx0 * 8 * HS;
   uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  // loop-invariant lane offsets of the colour stage (row-uniform layouts): the lane's 16-B luma
+  // chunk within a 64-chunk segment and its chroma chunk, both with the strip swizzle applied
+  // (the swizzle bit is bit 3 of the chunk index, which the segment number does not touch)
+  // (computed from an opaque copy of the lane id so they are materialised here, after the IDCT,
+  // instead of being kept in registers across it)
+  int lane_late = lane;
+  asm volatile("" : "+v"(lane_late));
+  const int lane_y_off = (lane_late ^ ((lane_late >> 3) & 1)) * 16;
+  const int lane_c_off = HS == 1 ? lane_y_off : (((lane_late >> 1) ^ ((lane_late >> 4) & 1)) * 16 + (lane_late & 1) * 8);
 
 #pragma unroll
   for (int phase = 0; phase < 2; phase++) {
@@ -380,61 +391,112 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     // 256 adjacent pixels (768 contiguous output bytes)
     const int y_base = my * 8 * VS + phase * YROWS;
     for (int it = wave; it < TASKS / 64; it += kTileBlocks / 64) {
-      int row, xq;
       if (kRowUniform) {
-        row = (it * 64) / TASKS_PER_ROW;  // scalar
-        xq = (it * 64) % TASKS_PER_ROW + lane;
+        // Everything but the data is wave-uniform here: the row, the 256-pixel segment of the row,
+        // the output address (a buffer descriptor per segment; lanes address it with the loop-
+        // invariant offset lane*12 and the hardware range check drops lanes past the image edge).
+        constexpr int IPR = TASKS_PER_ROW / 64;  // wave-iterations per strip row
+        const int row = it / IPR, seg = it - row * IPR;
+        const int y = y_base + row;
+        const int x_seg = tile_x0 + seg * 256;  // first pixel of this wave-iteration
+        if (y >= p.height || x_seg >= p.width) continue;
+        const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
+        float cb[4], cr[4];
+        // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
+        const int coff = (row / VS) * (CW * 4) + seg * (1024 / HS);
+        if (HS == 1) {
+          const float4 a = *(const float4 *)(lds + CB_OFF + lane_c_off + coff);
+          const float4 b = *(const float4 *)(lds + CR_OFF + lane_c_off + coff);
+          cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
+          cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
+        } else {
+          const float2 a = *(const float2 *)(lds + CB_OFF + lane_c_off + coff);
+          const float2 b = *(const float2 *)(lds + CR_OFF + lane_c_off + coff);
+          cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
+          cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
+        }
+        const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+        float r[4], g[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (JB_DO_COLOUR(p)) {
+            r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+            g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+            b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+          } else {
+            r[i] = yy[i], g[i] = cb[i], b[i] = cr[i];
+          }
+        }
+        if (!JB_DO_STORE(p)) continue;
+        uint8_t *const segp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x_seg * 3;
+        const int px_left = min(256, p.width - x_seg);  // pixels of this segment inside the image
+        if (p.fast_store) {
+          uint32_t w0, w1, w2;
+          pack12_rtz(r, g, b, w0, w1, w2);
+          // whole 4-pixel groups only: a group straddling the image edge is left to the tail below
+          const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (px_left >> 2) * 12, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, lane_late * 12, 0, 0);
+        }
+        if (!p.fast_store || (px_left & 3)) {
+          // unaligned output, or the one group that straddles the right edge: byte stores
+          const int first = p.fast_store ? (px_left & ~3) : 0;
+          int lane_tail = lane_late;  // opaque copy: keeps this rare path's address arithmetic
+          asm volatile("" : "+v"(lane_tail));  // from being hoisted out of the loop into registers
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int px = lane_tail * 4 + i;
+            if (px >= first && px < px_left) {
+              uint8_t *o = segp + px * 3;
+              o[0] = (uint8_t)pack_u8(r[i], 0, 0);
+              o[1] = (uint8_t)pack_u8(g[i], 0, 0);
+              o[2] = (uint8_t)pack_u8(b[i], 0, 0);
+            }
+          }
+        }
       } else {
         const int t = it * 64 + lane;
-        row = t / TASKS_PER_ROW;
-        xq = t - row * TASKS_PER_ROW;
-      }
-      const int x = tile_x0 + xq * 4, y = y_base + row;
-      if (y >= p.height || x >= p.width) continue;
-      const int c = xq ^ ((xq >> 3) & 1);  // swizzled chunk position
-      const float4 Y = *(const float4 *)(lds + row * (YW * 4) + c * 16);
-      float cb[4], cr[4];
-      // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
-      const int coff = (row / VS) * (CW * 4);
-      if (HS == 1) {
-        const float4 a = *(const float4 *)(lds + CB_OFF + coff + c * 16);
-        const float4 b = *(const float4 *)(lds + CR_OFF + coff + c * 16);
-        cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
-        cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
-      } else {
-        const int cc = xq >> 1;  // chroma chunk holding samples 2*xq, 2*xq+1
-        const int co = (cc ^ ((cc >> 3) & 1)) * 16 + (xq & 1) * 8;
-        const float2 a = *(const float2 *)(lds + CB_OFF + coff + co);
-        const float2 b = *(const float2 *)(lds + CR_OFF + coff + co);
-        cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
-        cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
-      }
-      const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
-      float r[4], g[4], b[4];
+        const int row = t / TASKS_PER_ROW;
+        const int xq = t - row * TASKS_PER_ROW;
+        const int x = tile_x0 + xq * 4, y = y_base + row;
+        if (y >= p.height || x >= p.width) continue;
+        const int c = xq ^ ((xq >> 3) & 1);  // swizzled chunk position
+        const float4 Y = *(const float4 *)(lds + row * (YW * 4) + c * 16);
+        float cb[4], cr[4];
+        const int coff = (row / VS) * (CW * 4);
+        if (HS == 1) {
+          const float4 a = *(const float4 *)(lds + CB_OFF + coff + c * 16);
+          const float4 b = *(const float4 *)(lds + CR_OFF + coff + c * 16);
+          cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
+          cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
+        } else {
+          const int cc = xq >> 1;  // chroma chunk holding samples 2*xq, 2*xq+1
+          const int co = (cc ^ ((cc >> 3) & 1)) * 16 + (xq & 1) * 8;
+          const float2 a = *(const float2 *)(lds + CB_OFF + coff + co);
+          const float2 b = *(const float2 *)(lds + CR_OFF + coff + co);
+          cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
+          cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
+        }
+        const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+        float r[4], g[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (JB_DO_COLOUR(p)) {
+        for (int i = 0; i < 4; i++) {
           r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
           g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
           b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
-        } else {
-          r[i] = yy[i], g[i] = cb[i], b[i] = cr[i];
         }
-      }
-      uint8_t *const rowp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)tile_x0 * 3;
-      uint8_t *const o = rowp + xq * 12;
-      if (!JB_DO_STORE(p)) continue;
-      if (p.fast_store && x + 4 <= p.width) {
-        uint32_t w0, w1, w2;
-        pack12_rtz(r, g, b, w0, w1, w2);
-        *(dw3_t *)o = dw3_t{w0, w1, w2};
-      } else {
+        uint8_t *const o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+        if (p.fast_store && x + 4 <= p.width) {
+          uint32_t w0, w1, w2;
+          pack12_rtz(r, g, b, w0, w1, w2);
+          *(dw3_t *)o = dw3_t{w0, w1, w2};
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          if (x + i < p.width) {
-            o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
-            o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
-            o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
+          for (int i = 0; i < 4; i++) {
+            if (x + i < p.width) {
+              o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
+              o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
+              o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
+            }
           }
         }
       }
