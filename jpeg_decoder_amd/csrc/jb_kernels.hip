@@ -346,7 +346,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   const int pitch = comp == 0 ? YW * 4 : CW * 4;
   const int blk_col = comp == 0 ? mcu * HS + bh : mcu;  // 8-sample column of the block in its strip
   const int sw = (blk_col >> 2) & 1;
-  char *const dst = lds + (comp == 0 ? 0 : (comp == 1 ? CB_OFF : CR_OFF)) + blk_col * 32;
+  char *const dst = lds + (comp == 0 ? bv * 4 * pitch : (comp == 1 ? CB_OFF : CR_OFF)) + blk_col * 32;
   char *const dst_lo = dst + sw * 16;        // samples 0..3 of a row
   char *const dst_hi = dst + (sw ^ 1) * 16;  // samples 4..7
 
@@ -369,18 +369,29 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
 #pragma unroll
   for (int phase = 0; phase < 2; phase++) {
     if (phase == 1) lds_barrier();  // phase-0 colour reads are done: the strips may be rewritten
-    if (VS == 2 && comp == 0) {
-      if (bv == phase) {
+    // Every lane contributes rows 4*phase..4*phase+3 of its block (so half of every block is
+    // consumed per phase and only 32 values wait in registers).  Luma block-row bv lands in
+    // strip rows 4*bv..4*bv+3 (VS == 2: the strip holds image rows 4p..4p+3 and 8+4p..8+4p+3);
+    // a chroma block contributes the chroma rows those luma rows need: row/VS of each, i.e.
+    // rows 2p, 2p+1, 4+2p, 5+2p for VS == 2 (reference jpeg.cpp:518-520).
+    if (VS == 1) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          *(float4 *)(dst_lo + k * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-          *(float4 *)(dst_hi + k * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
-        }
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = phase * 4 + kk;
+        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+      }
+    } else if (comp == 0) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = phase * 4 + kk;
+        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        const int k = phase * 4 + kk;
+        const int k = (kk >> 1) * 4 + phase * 2 + (kk & 1);
         *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
         *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
       }
@@ -389,7 +400,8 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
 
     // colour transform + store: one lane = 4 adjacent pixels of one row, one wave-iteration =
     // 256 adjacent pixels (768 contiguous output bytes)
-    const int y_base = my * 8 * VS + phase * YROWS;
+    // image row of strip row sr: block-row sr/4, row 4*phase + sr%4 within the block
+    const int y_base = my * 8 * VS + phase * 4;
     for (int it = wave; it < TASKS / 64; it += kTileBlocks / 64) {
       if (kRowUniform) {
         // Everything but the data is wave-uniform here: the row, the 256-pixel segment of the row,
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         // invariant offset lane*12 and the hardware range check drops lanes past the image edge).
         constexpr int IPR = TASKS_PER_ROW / 64;  // wave-iterations per strip row
         const int row = it / IPR, seg = it - row * IPR;
-        const int y = y_base + row;
+        const int y = y_base + (row >> 2) * 8 + (row & 3);
         const int x_seg = tile_x0 + seg * 256;  // first pixel of this wave-iteration
         if (y >= p.height || x_seg >= p.width) continue;
         const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         const int t = it * 64 + lane;
         const int row = t / TASKS_PER_ROW;
         const int xq = t - row * TASKS_PER_ROW;
-        const int x = tile_x0 + xq * 4, y = y_base + row;
+        const int x = tile_x0 + xq * 4, y = y_base + (row >> 2) * 8 + (row & 3);
         if (y >= p.height || x >= p.width) continue;
         const int c = xq ^ ((xq >> 3) & 1);  // swizzled chunk position
         const float4 Y = *(const float4 *)(lds + row * (YW * 4) + c * 16);

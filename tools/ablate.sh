@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for v in "" NO_LOAD NO_IDCT NO_COLOUR NO_MATH NO_STORE; do
   lib=$R/jpeg_decoder_amd/libjpegblk.so; [ -n "$v" ] && lib=$R/tools/libjpegblk_$v.so
-  JPEGBLK_LIB=$lib timeout -k 10 200 python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+  JPEGBLK_LIB=$lib timeout -k 10 200 python3 $R/bench.py --no-cpu-baseline $JB_BENCH_ARGS 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
