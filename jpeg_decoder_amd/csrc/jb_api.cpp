@@ -222,6 +222,7 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   if (n_tiles > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "batch too large for one launch (%lld tiles)", (long long)n_tiles);
   p.n_tiles = (int32_t)n_tiles;
   p.fast_store = (((uintptr_t)b->d_rgb & 3) == 0 && (b->rgb_row_stride & 3) == 0 && (b->rgb_image_stride & 3) == 0) ? 1 : 0;
+  p.chroma_q_equal = (b->desc.qtab_id[1] == b->desc.qtab_id[2]) ? 1 : 0;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   JB_HIP(ctx, jbk_launch(p, b->desc.hs, b->desc.vs, s));
   return JB_OK;

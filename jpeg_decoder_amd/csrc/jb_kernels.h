@@ -18,7 +18,9 @@ struct JbLaunch {
   int32_t tiles_per_row;      // ceil(mcus_x / jbk_mcus_per_tile(hs, vs))
   int32_t n_tiles;            // n_images * mcus_y * tiles_per_row = workgroups launched
   int32_t fast_store;         // 1 when rgb base and every stride are multiples of 4 bytes
-  int32_t reserved;
+  int32_t chroma_q_equal;     // 1 when Cb and Cr use the same table (desc.qtab_id[1] == qtab_id[2])
+  int32_t reserved;           // 0 (777 = skip switch of the timing-experiment builds)
+  int32_t pad_;
 };
 
 // MCUs covered by one workgroup (a tile is always 192 coded blocks): 64 / 48 / 32.

@@ -236,7 +236,13 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
   // 4:4:4: wave w owns component w, and its 8 KiB of coefficient bytes are exactly the 8 KiB its
   // strip occupies, so loading and consuming the coefficients needs no workgroup barrier.
-  constexpr bool kWavePrivate = (NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192);
+  // 4:2:0: waves 0 and 1 hold the luma blocks of MCUs 0-15 / 16-31, i.e. pixel columns 0-255 /
+  // 256-511 of the tile; storing the luma strip as two 8 KiB half-strips ([wave][row][256 px])
+  // and the chroma strips (4 KiB each) behind them makes every wave's strip its own 8 KiB too.
+  constexpr bool kSplitY = (HS == 2 && VS == 2);
+  constexpr bool kWavePrivate = ((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192)) || kSplitY;
+  constexpr int Y_ROW_PITCH = kSplitY ? 1024 : YW * 4;  // bytes between luma strip rows
+  constexpr int Y_SEG_PITCH = kSplitY ? 8192 : 1024;    // bytes between 256-pixel segments of a row
 
   __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
   const int tid = threadIdx.x;
@@ -298,7 +304,10 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     if (!kWavePrivate) lds_barrier();  // every lane holds its block: the bytes may be overwritten
 
     // dequantise (jpeg.cpp:563-569): int32 product, int->float on first use (jpeg.cpp:598)
-    if (kWavePrivate || comp_a == comp_b) {
+    constexpr bool kUniformWaves = (NYT % 64 == 0) && (MCUS % 64 == 0);  // 4:4:4: one component per wave
+    // p.chroma_q_equal: Cb and Cr name the same table (the usual case), so a wave that mixes
+    // Cb and Cr blocks is still uniform as far as dequantisation goes
+    if (kUniformWaves || comp_a == comp_b || (p.chroma_q_equal && comp_a != 0)) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
 #pragma unroll
@@ -343,10 +352,11 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   // c ^ ((c>>3)&1) so that the 8 lanes of a ds_write_b128 group hit 8 different bank quads.
   const int bv = comp == 0 ? slot / HS : 0;
   const int bh = comp == 0 ? slot - bv * HS : 0;
-  const int pitch = comp == 0 ? YW * 4 : CW * 4;
+  const int pitch = comp == 0 ? Y_ROW_PITCH : CW * 4;
   const int blk_col = comp == 0 ? mcu * HS + bh : mcu;  // 8-sample column of the block in its strip
   const int sw = (blk_col >> 2) & 1;
-  char *const dst = lds + (comp == 0 ? bv * 4 * pitch : (comp == 1 ? CB_OFF : CR_OFF)) + blk_col * 32;
+  const int luma_off = bv * 4 * Y_ROW_PITCH + (kSplitY ? (blk_col >> 5) * Y_SEG_PITCH + (blk_col & 31) * 32 : blk_col * 32);
+  char *const dst = lds + (comp == 0 ? luma_off : (comp == 1 ? CB_OFF : CR_OFF) + blk_col * 32);
   char *const dst_lo = dst + sw * 16;        // samples 0..3 of a row
   char *const dst_hi = dst + (sw ^ 1) * 16;  // samples 4..7
 
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         const int y = y_base + (row >> 2) * 8 + (row & 3);
         const int x_seg = tile_x0 + seg * 256;  // first pixel of this wave-iteration
         if (y >= p.height || x_seg >= p.width) continue;
-        const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
+        const float4 Y = *(const float4 *)(lds + lane_y_off + row * Y_ROW_PITCH + seg * Y_SEG_PITCH);
         float cb[4], cr[4];
         // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
         const int coff = (row / VS) * (CW * 4) + seg * (1024 / HS);
