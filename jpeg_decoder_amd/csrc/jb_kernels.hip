@@ -7,26 +7,27 @@
 // Work decomposition (wave64, no MFMA -- this is 8-point butterflies, not a GEMM):
 //   * a workgroup (3 waves, 192 lanes) owns one TILE = a run of 192/NB consecutive MCUs of one
 //     MCU row (NB = hs*vs + 2 coded blocks per MCU): 64 MCUs in 4:4:4, 32 in 4:2:0, 48 in
-//     4:2:2 / 4:4:0 -- always 192 coded blocks = 24 KiB of contiguous int16 coefficients in,
-//     192*64 luma-resolution... pixels out.
-//   * stage 1, HBM -> LDS: the tile's coefficient bytes are copied by 8 rounds of
-//     global_load_lds_dwordx4 (LDS-DMA: no VGPRs, 1 KiB contiguous per wave-instruction, whole
-//     128-B lines).  The 16-B chunks of block n land at chunk position j ^ ((n>>1)&7) -- the
-//     swizzle is applied to the per-lane GLOBAL source address because LDS-DMA writes LDS
-//     linearly -- so that the 128-B-strided ds_read_b128 of stage 2 is bank-conflict free.
-//   * stage 2, one lane = one coded 8x8 block: 8 ds_read_b128 fetch the block, then dequantise
-//     and 16 1-D AAN passes run entirely in that lane's registers with static indexing (no
-//     cross-lane traffic, no redundant arithmetic).  Lanes take blocks sorted by component, so
-//     the quantisation table is wave-uniform (SGPRs via scalar loads) wherever possible.
-//   * stage 3, twice (upper / lower half of the tile's pixel rows): the lanes write the
-//     integer-valued f32 samples of that half into planar strips in LDS (Y strip 4*vs rows, Cb and
-//     Cr strips 4 rows: 24 KiB, overlaying the consumed coefficient bytes; the other half waits
-//     in registers), then one lane = 4 horizontally adjacent pixels: ds_read_b128 of Y, the
-//     (replicated) chroma samples, the colour transform, pack to 12 bytes and ONE
-//     global_store_dwordx3; consecutive lanes are consecutive in the image row, so a
-//     wave-instruction writes 768 contiguous bytes (six whole 128-B lines).
-//     Halving the strips keeps a workgroup at 24.8 KiB of LDS = 6 workgroups (18 waves) per CU,
-//     which is what hides the HBM latency of stage 1 behind other workgroups' arithmetic.
+//     4:2:2 / 4:4:0 -- always 192 coded blocks = 24 KiB of contiguous int16 coefficients in.
+//     blockIdx -> tile is XCD-aware (each XCD gets one contiguous band of tiles).
+//   * stage 1+2, one lane = one coded 8x8 block.  Lanes take the tile's blocks sorted by
+//     component, so the quantisation table is wave-uniform (scalar loads -> SGPRs) wherever
+//     possible (4:4:4: wave w = component w).  The lane's 128 coefficient bytes reach 32 VGPRs
+//     either straight from HBM (8 global_load_dwordx4 per lane; measured 6.4-6.5 TB/s although
+//     every lane of an instruction touches a different line, tools/probe_load.hip) or, in 4:4:4
+//     where it measured 4 % faster, through LDS-DMA (global_load_lds_dwordx4) into the wave's own
+//     8 KiB of LDS with an XOR swizzle that makes the 128-B-strided ds_read_b128 conflict free.
+//     Then dequantise and 16 1-D AAN passes run entirely in that lane's registers with static
+//     indexing (no cross-lane traffic, no redundant arithmetic).
+//   * stage 3, twice (rows 0-3 / rows 4-7 of every block): the lanes write the integer-valued
+//     f32 samples of that half into planar strips in LDS (Y, Cb, Cr: 24 KiB; the other half waits
+//     in registers), XOR-swizzled per 16-B chunk so ds_write_b128 is conflict free; then one lane =
+//     4 horizontally adjacent pixels: ds_read_b128 of Y, the (replicated) chroma samples, the
+//     colour transform, a 12-byte pack under round-toward-zero mode, and ONE
+//     buffer_store_dwordx3 whose descriptor range check drops lanes past the image edge.
+//     Consecutive lanes are consecutive in the image row: a wave-instruction writes 768
+//     contiguous bytes (six whole 128-B lines).  All per-iteration addressing is scalar.
+//     Two phases keep a workgroup at 24 KiB of LDS = 6 workgroups (18 waves) per CU; the 3
+//     workgroup barriers per tile order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
 //
 // Arithmetic is bit-exact with the reference: int32 dequantise (v_mul_i32_i24), the AAN graph
 // of jpeg.cpp:598-662 evaluated in the same order with separate IEEE mul/add (this TU is built
@@ -66,10 +67,7 @@ __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(f
 #define JB_CB_B kf(0x3FE2D0E5u)
 
 constexpr int kTileBlocks = 192;                  // coded blocks per tile = lanes per workgroup
-constexpr int kRawBytes = kTileBlocks * 128;      // 24 KiB of int16 coefficients
 constexpr int kStripBytes = kTileBlocks * 128;    // 24 KiB: half of the tile's f32 samples
-constexpr int kLdsBytes = kRawBytes;
-static_assert(kStripBytes <= kRawBytes, "strips overlay the consumed coefficient bytes");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for the
 // global stores of the previous colour phase (vmcnt(0)), putting HBM write latency on the
@@ -234,17 +232,8 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
   constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
-  // 4:4:4: wave w owns component w, and its 8 KiB of coefficient bytes are exactly the 8 KiB its
-  // strip occupies, so loading and consuming the coefficients needs no workgroup barrier.
-  // 4:2:0: waves 0 and 1 hold the luma blocks of MCUs 0-15 / 16-31, i.e. pixel columns 0-255 /
-  // 256-511 of the tile; storing the luma strip as two 8 KiB half-strips ([wave][row][256 px])
-  // and the chroma strips (4 KiB each) behind them makes every wave's strip its own 8 KiB too.
-  constexpr bool kSplitY = (HS == 2 && VS == 2);
-  constexpr bool kWavePrivate = ((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192)) || kSplitY;
-  constexpr int Y_ROW_PITCH = kSplitY ? 1024 : YW * 4;  // bytes between luma strip rows
-  constexpr int Y_SEG_PITCH = kSplitY ? 8192 : 1024;    // bytes between 256-pixel segments of a row
-
-  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  constexpr bool kDirectLoad = !((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192));  // all but 4:4:4
+  __shared__ __attribute__((aligned(1024))) char lds[kStripBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,21 +263,6 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
                              ((int64_t)my * p.mcus_x + mx0) * (NB * 128);
   const q_const_t *qsrc = (const q_const_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
 
-  // ---- stage 1: coefficients HBM -> LDS by LDS-DMA.  Each wave fetches exactly the 64 blocks
-  // its own lanes will read: block of lane l at wave*8 KiB + l*128, 16-B chunk j at position
-  // j ^ ((l>>1)&7).  Every 8 lanes fetch one whole 128-B line. ----
-  char *const wave_lds = lds + wave * 8192;
-  if (JB_DO_LOAD(p))
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int l2 = i * 8 + (lane >> 3);  // the lane whose block this chunk belongs to
-    const int f = (l2 >> 1) & 7;
-    const int nsrc = min(LM::block(wave * 64 + l2), last_block);  // ragged tile: re-read its last block
-    const uint32_t off = (uint32_t)nsrc * 128u + (uint32_t)(((lane & 7) ^ f) << 4);
-    const uint8_t *src = tile_coef + off;
-    __builtin_amdgcn_global_load_lds((gbl_void_t *)src, (lds_void_t *)(wave_lds + i * 1024), 16, 0, 0);
-  }
-
   // ---- stage 2: this lane's block -> registers ----
   const int comp = LM::comp(tid);
   const int mcu = LM::mcu(tid);    // MCU within the tile
@@ -299,21 +273,53 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   const q_const_t *qb = qsrc + comp_b * 64;
   float v[64];
   {
+    // ---- stage 1: this lane's block (128 contiguous bytes) -> 32 VGPRs.  Default: straight from
+    // HBM with 8 dwordx4 loads.  Every lane of a wave-instruction touches a different 128-B line,
+    // but the 8 instructions of the wave consume those 64 lines completely: measured 6.4-6.5 TB/s
+    // on MI355X (tools/probe_load.hip), the same as perfectly coalesced loads.
     uint32_t raw[32];  // row k = dwords 4k..4k+3, two int16 (columns 2j, 2j+1) per dword
-    const int f = (lane >> 1) & 7;
-    const char *base = wave_lds + lane * 128;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!kWavePrivate) lds_barrier();
+    if (kDirectLoad) {
+      const int n = min(LM::block(tid), last_block);  // ragged tile: re-read its last block
+      const uint4 *src = (const uint4 *)(tile_coef + (uint32_t)n * 128u);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint4 t = *(const uint4 *)(base + ((j ^ f) << 4));
-      raw[j * 4 + 0] = t.x;
-      raw[j * 4 + 1] = t.y;
-      raw[j * 4 + 2] = t.z;
-      raw[j * 4 + 3] = t.w;
+      for (int j = 0; j < 8; j++) {
+        const uint4 t = JB_DO_LOAD(p) ? src[j] : make_uint4(0, 0, 0, 0);
+        raw[j * 4 + 0] = t.x;
+        raw[j * 4 + 1] = t.y;
+        raw[j * 4 + 2] = t.z;
+        raw[j * 4 + 3] = t.w;
+      }
+    } else {
+      // 4:4:4 only (measured 4 % faster there than the direct loads): LDS-DMA
+      // (global_load_lds_dwordx4: no VGPRs, 1 KiB per wave-instruction, every 8 lanes fetch one
+      // whole 128-B line).  Wave w = component w fetches exactly the 64 blocks its own lanes
+      // consume into its own 8 KiB of LDS -- the same 8 KiB its strip occupies later -- so neither
+      // the load nor the hand-over to the strips needs a workgroup barrier.  Chunk j of the block
+      // of lane l lands at chunk position j ^ ((l>>1)&7) (applied to the per-lane GLOBAL address,
+      // LDS-DMA writes LDS linearly), which makes the 128-B-strided ds_read_b128 conflict free.
+      char *const wave_lds = lds + wave * 8192;
+      if (JB_DO_LOAD(p))
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int l2 = i * 8 + (lane >> 3);  // the lane whose block this chunk belongs to
+          const int f2 = (l2 >> 1) & 7;
+          const int nsrc = min(LM::block(wave * 64 + l2), last_block);
+          const uint32_t off = (uint32_t)nsrc * 128u + (uint32_t)(((lane & 7) ^ f2) << 4);
+          __builtin_amdgcn_global_load_lds((gbl_void_t *)(tile_coef + off), (lds_void_t *)(wave_lds + i * 1024), 16, 0, 0);
+        }
+      const int f = (lane >> 1) & 7;
+      const char *base = wave_lds + lane * 128;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint4 t = *(const uint4 *)(base + ((j ^ f) << 4));
+        raw[j * 4 + 0] = t.x;
+        raw[j * 4 + 1] = t.y;
+        raw[j * 4 + 2] = t.z;
+        raw[j * 4 + 3] = t.w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!kWavePrivate) lds_barrier();  // every lane holds its block: the bytes may be overwritten
 
     // dequantise (jpeg.cpp:563-569): int32 product, int->float on first use (jpeg.cpp:598)
     constexpr bool kUniformWaves = (NYT % 64 == 0) && (MCUS % 64 == 0);  // 4:4:4: one component per wave
@@ -364,10 +370,10 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   // c ^ ((c>>3)&1) so that the 8 lanes of a ds_write_b128 group hit 8 different bank quads.
   const int bv = comp == 0 ? slot / HS : 0;
   const int bh = comp == 0 ? slot - bv * HS : 0;
-  const int pitch = comp == 0 ? Y_ROW_PITCH : CW * 4;
+  const int pitch = comp == 0 ? (YW * 4) : CW * 4;
   const int blk_col = comp == 0 ? mcu * HS + bh : mcu;  // 8-sample column of the block in its strip
   const int sw = (blk_col >> 2) & 1;
-  const int luma_off = bv * 4 * Y_ROW_PITCH + (kSplitY ? (blk_col >> 5) * Y_SEG_PITCH + (blk_col & 31) * 32 : blk_col * 32);
+  const int luma_off = bv * 4 * (YW * 4) + blk_col * 32;
   char *const dst = lds + (comp == 0 ? luma_off : (comp == 1 ? CB_OFF : CR_OFF) + blk_col * 32);
   char *const dst_lo = dst + sw * 16;        // samples 0..3 of a row
   char *const dst_hi = dst + (sw ^ 1) * 16;  // samples 4..7
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         const int y = y_base + (row >> 2) * 8 + (row & 3);
         const int x_seg = tile_x0 + seg * 256;  // first pixel of this wave-iteration
         if (y >= p.height || x_seg >= p.width) continue;
-        const float4 Y = *(const float4 *)(lds + lane_y_off + row * Y_ROW_PITCH + seg * Y_SEG_PITCH);
+        const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
         float cb[4], cr[4];
         // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
         const int coff = (row / VS) * (CW * 4) + seg * (1024 / HS);
