@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, HS, VS = 4096, 4096, 1, 1
 IMAGES_PER_STEP = 8
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SAMPLING_NAME = {(1, 1): "4:4:4", (2, 2): "4:2:0", (2, 1): "4:2:2", (1, 2): "4:4:0"}
 
 
 def cpu_baseline(coef, qtabs, budget_s=12.0):
@@ -179,9 +180,9 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"stream of {WIDTH}x{HEIGHT} baseline {args.workload.split('-')[1]} images, {nimg} images per step "
+            "config": {"workload": f"stream of {WIDTH}x{HEIGHT} baseline {SAMPLING_NAME[(HS, VS)]} images, {nimg} images per step "
                                    f"(one launch) per GPU, coefficient blocks resident in HBM",
-                       "images_per_step_per_gpu": nimg, "sampling": {(1, 1): "4:4:4", (2, 2): "4:2:0", (2, 1): "4:2:2", (1, 2): "4:4:0"}[(HS, VS)], "parallelism": f"images sharded x{n_gpus}, no collective"},
+                       "images_per_step_per_gpu": nimg, "sampling": SAMPLING_NAME[(HS, VS)], "parallelism": f"images sharded x{n_gpus}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": jb.lib().jb_kernel_name(desc).decode(), "algorithmic_bytes_per_launch": alg_bytes,
