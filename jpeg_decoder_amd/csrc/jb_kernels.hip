@@ -82,8 +82,9 @@ __device__ __forceinline__ void lds_barrier() {
 
 // One 1-D pass of the AAN network (reference jpeg.cpp:598-662 / 666-730), in place, each
 // output truncated toward zero exactly where the reference stores a float into an int.
-__device__ __forceinline__ void aan_1d(float &x0, float &x1, float &x2, float &x3, float &x4,
-                                       float &x5, float &x6, float &x7) {
+__device__ __forceinline__ void aan_1d_io(float x0, float x1, float x2, float x3, float x4, float x5,
+                                          float x6, float x7, float &y0, float &y1, float &y2,
+                                          float &y3, float &y4, float &y5, float &y6, float &y7) {
   const float g0 = x0 * JB_S0;
   const float g1 = x4 * JB_S4;
   const float g2 = x2 * JB_S2;
@@ -125,14 +126,20 @@ __device__ __forceinline__ void aan_1d(float &x0, float &x1, float &x2, float &x
   const float b4 = c4 - c8;
   const float b6 = c6 - e7;
 
-  x0 = __builtin_truncf(b0 + e7);
-  x1 = __builtin_truncf(b1 + b6);
-  x2 = __builtin_truncf(b2 + c8);
-  x3 = __builtin_truncf(b3 + b4);
-  x4 = __builtin_truncf(b3 - b4);
-  x5 = __builtin_truncf(b2 - c8);
-  x6 = __builtin_truncf(b1 - b6);
-  x7 = __builtin_truncf(b0 - e7);
+  y0 = __builtin_truncf(b0 + e7);
+  y1 = __builtin_truncf(b1 + b6);
+  y2 = __builtin_truncf(b2 + c8);
+  y3 = __builtin_truncf(b3 + b4);
+  y4 = __builtin_truncf(b3 - b4);
+  y5 = __builtin_truncf(b2 - c8);
+  y6 = __builtin_truncf(b1 - b6);
+  y7 = __builtin_truncf(b0 - e7);
+}
+
+// in place
+__device__ __forceinline__ void aan_1d(float &x0, float &x1, float &x2, float &x3, float &x4,
+                                       float &x5, float &x6, float &x7) {
+  aan_1d_io(x0, x1, x2, x3, x4, x5, x6, x7, x0, x1, x2, x3, x4, x5, x6, x7);
 }
 
 __device__ __forceinline__ uint32_t pack_u8(float x, uint32_t byte, uint32_t old) {
@@ -222,7 +229,12 @@ struct LaneMap {
 };
 
 // One workgroup (192 lanes) per tile.  See the file header for the three stages.
-template <int HS, int VS>
+// MIXQ = false: every wave dequantises with ONE table (4:4:4 always; 4:2:0 when Cb and Cr name the
+// same table, the usual case).  MIXQ = true: a wave may hold blocks of two components with
+// different tables and selects per lane; kept out of the MIXQ = false instantiation because its
+// register pressure would cost the common case a wave per SIMD.
+template <int HS, int VS, bool MIXQ>
+// (forcing 5 waves/SIMD on the 4:2:0 instantiation spills 7 registers and measured 9 % slower)
 __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   using LM = LaneMap<HS, VS>;
   constexpr int NB = LM::NB, MCUS = LM::MCUS, NYT = LM::NYT;
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
   constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
+  constexpr bool kPermChroma = (VS == 2) && (NYT % 64 == 0);  // 4:2:0: chroma blocks fill a whole wave
   constexpr bool kDirectLoad = !((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192));  // all but 4:4:4
   __shared__ __attribute__((aligned(1024))) char lds[kStripBytes];
   const int tid = threadIdx.x;
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     constexpr bool kUniformWaves = (NYT % 64 == 0) && (MCUS % 64 == 0);  // 4:4:4: one component per wave
     // p.chroma_q_equal: Cb and Cr name the same table (the usual case), so a wave that mixes
     // Cb and Cr blocks is still uniform as far as dequantisation goes
-    if (kUniformWaves || comp_a == comp_b || (p.chroma_q_equal && comp_a != 0)) {
+    if (!MIXQ || kUniformWaves || comp_a == comp_b || (p.chroma_q_equal && comp_a != 0)) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
 #pragma unroll
@@ -352,10 +365,24 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     }
   }
   if (JB_DO_IDCT(p)) {
+  // 4:2:0: a chroma block is needed as rows {0,1,4,5} in the first colour phase and {2,3,6,7} in
+  // the second (chroma row r covers luma rows 2r, 2r+1), a luma block as rows 0-3 / 4-7.  The
+  // chroma wave therefore stores column-pass output row k in register row sigma(k), sigma =
+  // (0 1 4 5 2 3 6 7), so that for every lane "register rows 0-3" is what phase 0 consumes and
+  // only 32 registers have to wait for phase 1.  (Row passes do not care which row they hold.)
+  if (kPermChroma && comp_a != 0) {
 #pragma unroll
-  for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
-    aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
-           v[6 * 8 + i], v[7 * 8 + i]);
+    for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663, outputs permuted by sigma
+      aan_1d_io(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
+                v[6 * 8 + i], v[7 * 8 + i],  //
+                v[0 * 8 + i], v[1 * 8 + i], v[4 * 8 + i], v[5 * 8 + i], v[2 * 8 + i], v[3 * 8 + i],
+                v[6 * 8 + i], v[7 * 8 + i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
+      aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
+             v[6 * 8 + i], v[7 * 8 + i]);
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
@@ -402,7 +429,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     // strip rows 4*bv..4*bv+3 (VS == 2: the strip holds image rows 4p..4p+3 and 8+4p..8+4p+3);
     // a chroma block contributes the chroma rows those luma rows need: row/VS of each, i.e.
     // rows 2p, 2p+1, 4+2p, 5+2p for VS == 2 (reference jpeg.cpp:518-520).
-    if (VS == 1) {
+    if (VS == 1 || kPermChroma) {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const int k = phase * 4 + kk;
@@ -546,7 +573,15 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
 
 template <int HS, int VS>
 static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
-  hipLaunchKernelGGL((jb_tile_kernel<HS, VS>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
+  using LM = LaneMap<HS, VS>;
+  // does any wave hold two components whose tables may differ?
+  constexpr bool kLumaChromaMixed = (LM::NYT % 64 != 0);                      // 4:2:2, 4:4:0
+  constexpr bool kCbCrMixed = (LM::MCUS % 64 != 0);                           // all but 4:4:4
+  const bool mixq = kLumaChromaMixed || (kCbCrMixed && !p.chroma_q_equal);
+  if (mixq)
+    hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
+  else
+    hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
   return hipGetLastError();
 }
 
@@ -562,8 +597,8 @@ hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
 }
 
 const char *jbk_kernel_name(int hs, int vs) {
-  if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1>";
-  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1>";
-  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2>";
-  return "jb_tile_kernel<2, 2>";
+  if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1, false>";
+  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1, true>";
+  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2, true>";
+  return "jb_tile_kernel<2, 2, false>";  // <2, 2, true> when Cb and Cr use different tables
 }
