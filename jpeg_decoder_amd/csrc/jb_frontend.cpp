@@ -49,6 +49,10 @@ struct HuffTable {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
   uint16_t fast[512];
+  // AC tables only: 9-bit lookahead that resolves code AND magnitude bits in one step when both
+  // fit in 9 bits: (value << 8) | (run << 4) | (code length + magnitude bits); 0 = take the
+  // general path
+  int16_t fast_ac[512];
 
   bool build() {
     int code = 0, k = 0;
@@ -71,6 +75,17 @@ struct HuffTable {
         for (int j = 0; j < (1 << (9 - len)); j++) fast[first + j] = (uint16_t)((len << 8) | symbols[k]);
       }
       code <<= 1;
+    }
+    // combined code + magnitude lookup (T.81 F.2.2.1 EXTEND folded in)
+    for (int i = 0; i < 512; i++) {
+      fast_ac[i] = 0;
+      const uint16_t f = fast[i];
+      if (!f) continue;
+      const int len = f >> 8, rs = f & 0xff, run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > 9) continue;
+      int k = ((i << len) & 511) >> (9 - mag);  // the magnitude bits that follow the code
+      if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;
+      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)((k * 256) + (run * 16) + (len + mag));
     }
     set = true;
     return true;
@@ -114,6 +129,23 @@ struct BitReader {
   BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
 
   inline void refill() {
+    // fast path: 8 bytes at once when none of them is 0xFF (no stuffing, no marker)
+    if (!marker && p + 8 <= end) {
+      uint64_t w;
+      memcpy(&w, p, 8);
+      const uint64_t nw = ~w;  // a 0xFF byte in w is a zero byte in ~w
+      if ((((nw - 0x0101010101010101ull) & ~nw) & 0x8080808080808080ull) == 0) {
+        w = __builtin_bswap64(w);
+        const int take = (64 - nbits) >> 3;  // whole bytes that fit
+        if (take > 0) {
+          const uint64_t m = take == 8 ? ~0ull : ~(~0ull >> (8 * take));
+          acc |= (w & m) >> nbits;
+          p += take;
+          nbits += 8 * take;
+        }
+        return;
+      }
+    }
     while (nbits <= 56) {
       uint32_t byte = 0;
       if (!marker && p < end) {
@@ -172,7 +204,7 @@ struct BitReader {
 };
 
 inline int decode_symbol(BitReader &br, const HuffTable &t) {
-  br.refill();
+  if (br.nbits < 32) br.refill();
   const uint32_t look = br.peek(9);
   const uint16_t f = t.fast[look];
   if (f) {
@@ -200,13 +232,21 @@ inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac
   memset(out, 0, 128);
   const int s = decode_symbol(br, dc);
   if (s < 0 || s > 11) return false;
-  br.refill();
-  const int diff = s ? extend(br.get(s), s) : 0;
+  const int diff = s ? extend(br.get(s), s) : 0;  // decode_symbol left >= 16 bits buffered
   pred += diff;
   if (pred < -32768 || pred > 32767) return false;
   out[0] = (int16_t)pred;
   int k = 1;
   while (k < 64) {
+    if (br.nbits < 32) br.refill();
+    const int fa = ac.fast_ac[br.peek(9)];
+    if (fa) {  // code and magnitude resolved by one lookup
+      k += (fa >> 4) & 15;
+      if (k > 63) return false;  // reference jpeg.cpp:372-376
+      br.drop(fa & 15);
+      out[kZigZag[k++]] = (int16_t)(fa >> 8);
+      continue;
+    }
     const int rs = decode_symbol(br, ac);
     if (rs < 0) return false;
     if (rs == 0) break;  // EOB
@@ -216,8 +256,7 @@ inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac
     if (k + r >= 64 || n > 10) return false;  // reference jpeg.cpp:372-385
     k += r;
     if (n) {
-      br.refill();
-      out[kZigZag[k]] = (int16_t)extend(br.get(n), n);
+      out[kZigZag[k]] = (int16_t)extend(br.get(n), n);  // <= 16 + 10 bits since the last refill
       k++;
     }
   }
