@@ -129,3 +129,60 @@ def test_write_ppm(jb, tmp_path):
     assert jb.lib().jb_write_ppm(str(p).encode(), rgb.ctypes.data, 5, 3, 15) == 0
     raw = p.read_bytes()
     assert raw.startswith(b"P6\n5 3\n255\n") and raw[len(b"P6\n5 3\n255\n"):] == rgb.tobytes()
+
+
+def _pil_jpeg(img, **kw):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", optimize=False, **kw)
+    return b.getvalue()
+
+
+def test_front_end_restart_intervals_any_length(jb):
+    """Restart intervals are counted in MCUs (T.81), whatever their length: the same picture
+    written with and without DRI (1, 2, 5, 11 MCUs per interval -- none a whole MCU row) decodes
+    to identical coefficient blocks in 4:4:4, 4:2:2 and 4:2:0.  (The reference's own restart test,
+    jpeg.cpp:414-419, only works for whole-row intervals such as its bundled img4.jpg, which
+    test_front_end_matches_reference_coefficients pins.)"""
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(3)
+    img = np.clip(np.cumsum(rng.normal(0, 6, (93, 157, 3)), axis=1) + 128, 0, 255).astype(np.uint8)
+    for sub, hsvs in ((0, (1, 1)), (1, (2, 1)), (2, (2, 2))):
+        d0, q0, c0 = jb.entropy_decode(_pil_jpeg(img, quality=85, subsampling=sub))
+        assert (d0.hs, d0.vs) == hsvs and (d0.width, d0.height) == (157, 93)
+        for blocks in (1, 2, 5, 11):
+            data = _pil_jpeg(img, quality=85, subsampling=sub, restart_marker_blocks=blocks)
+            assert b"\xff\xdd" in data
+            d, q, c = jb.entropy_decode(data)
+            assert np.array_equal(q, q0) and np.array_equal(c, c0), (sub, blocks)
+        # a missing restart marker is an error, not a silent mis-decode
+        data = bytearray(_pil_jpeg(img, quality=85, subsampling=sub, restart_marker_blocks=5))
+        pos = data.index(b"\xff\xd0", data.index(b"\xff\xda"))
+        data[pos + 1] = 0x00  # FF D0 -> FF 00 (a stuffed FF byte)
+        with pytest.raises(jb.JbError):
+            jb.entropy_decode(bytes(data))
+
+
+def test_front_end_sixteen_bit_quant_table(jb):
+    """Pq = 1 tables keep all 16 bits (the reference keeps the low byte, jpeg.cpp:216)."""
+    pytest.importorskip("PIL")
+    img = np.full((16, 16, 3), 128, np.uint8)
+    data = bytearray(_pil_jpeg(img, quality=90, subsampling=0))
+    dqt = data.index(b"\xff\xdb")
+    seglen = (data[dqt + 2] << 8) | data[dqt + 3]
+    assert data[dqt + 4] == 0x00  # Pq = 0, Tq = 0, 64 one-byte entries
+    tab8 = bytes(data[dqt + 5:dqt + 5 + 64])
+    tab16 = b"".join(bytes([1 if i == 5 else 0, v]) for i, v in enumerate(tab8))  # entry 5 += 256
+    new_seg = b"\xff\xdb" + (2 + 1 + 128).to_bytes(2, "big") + b"\x10" + tab16
+    rest = data[dqt + 2 + seglen:]
+    if seglen > 2 + 65:  # a second table lives in the same segment: keep it as its own segment
+        tail = bytes(data[dqt + 5 + 64:dqt + 2 + seglen])
+        new_seg += b"\xff\xdb" + (2 + len(tail)).to_bytes(2, "big") + tail
+    patched = bytes(data[:dqt]) + new_seg + bytes(rest)
+    d, q, c = jb.entropy_decode(patched)
+    d0, q0, c0 = jb.entropy_decode(bytes(data))
+    want = q0.copy()
+    zz5 = 2  # zig-zag position 5 is natural index 2
+    want[0, zz5] += 256
+    assert np.array_equal(q, want) and np.array_equal(c, c0)

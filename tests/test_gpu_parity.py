@@ -255,3 +255,25 @@ def test_decode_batch_threads_and_failures(jb, tmp_path):
     # single thread, clean batch
     imgs, statuses, times = jb.decode_batch(paths[:4], n_threads=1)
     assert times["rc"] == 0 and all(s == 0 for s in statuses)
+
+
+def test_decode_pil_files_all_layouts_with_restarts(jb, big_ctx, oracle, tmp_path):
+    """decode(path) on encoder-made files the reference has no fixtures for (4:2:2, 4:2:0 and
+    4:4:4 with restart intervals): front end + device seam == oracle on the decoded blocks."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from oracle.pyoracle import make_desc as odesc
+    rng = np.random.default_rng(11)
+    img = np.clip(np.cumsum(rng.normal(0, 5, (211, 333, 3)), axis=0) + 120, 0, 255).astype(np.uint8)
+    for sub in (0, 1, 2):
+        for restart in (0, 7):
+            p = tmp_path / f"s{sub}_r{restart}.jpg"
+            kw = {"restart_marker_blocks": restart} if restart else {}
+            Image.fromarray(img).save(p, "JPEG", quality=92, subsampling=sub, optimize=False, **kw)
+            desc, q, coef = jb.entropy_decode(p.read_bytes())
+            want = oracle.blocks_to_rgb(odesc(desc.width, desc.height, desc.hs, desc.vs, list(desc.qtab_id)), coef, q)
+            got = big_ctx.decode_file(str(p))
+            assert np.array_equal(got, want), (sub, restart)
+            # sanity: the picture is recognisably the input (the reference's IDCT is not the
+            # encoder's inverse to the last bit, so only a loose bound)
+            assert np.abs(got.astype(int) - img.astype(int)).mean() < 6
