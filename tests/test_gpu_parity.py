@@ -264,7 +264,9 @@ def test_decode_pil_files_all_layouts_with_restarts(jb, big_ctx, oracle, tmp_pat
     from PIL import Image
     from oracle.pyoracle import make_desc as odesc
     rng = np.random.default_rng(11)
-    img = np.clip(np.cumsum(rng.normal(0, 5, (211, 333, 3)), axis=0) + 120, 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:211, 0:333]
+    img = np.clip(np.stack([xx * 0.6 + yy * 0.2, 200 - yy * 0.7, (xx + yy) * 0.35 + 30], -1)
+                  + rng.normal(0, 2, (211, 333, 3)), 0, 255).astype(np.uint8)
     for sub in (0, 1, 2):
         for restart in (0, 7):
             p = tmp_path / f"s{sub}_r{restart}.jpg"
@@ -276,4 +278,4 @@ def test_decode_pil_files_all_layouts_with_restarts(jb, big_ctx, oracle, tmp_pat
             assert np.array_equal(got, want), (sub, restart)
             # sanity: the picture is recognisably the input (the reference's IDCT is not the
             # encoder's inverse to the last bit, so only a loose bound)
-            assert np.abs(got.astype(int) - img.astype(int)).mean() < 6
+            assert np.abs(got.astype(int) - img.astype(int)).mean() < 8
