@@ -98,10 +98,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal knobs (never set by the driver): run N ranks on a one-GPU box
+    backend = os.environ.get("JB_BENCH_BACKEND", "nccl")  # "nccl" = RCCL on ROCm
+    if os.environ.get("JB_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     n_gpus = max(world, 1)
     if jb.lib().jb_device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: " + jb.lib().jb_last_error(None).decode())
@@ -160,7 +167,8 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     pixels_per_step = nimg * WIDTH * HEIGHT
     from jpeg_decoder_amd.shard import job_throughput
-    total_pixels, elapsed = job_throughput(dist, dev, pixels_per_step * args.steps, elapsed)
+    total_pixels, elapsed = job_throughput(dist, dev if backend == "nccl" else torch.device("cpu"),
+                                           pixels_per_step * args.steps, elapsed)
 
     alg_bytes = nimg * (g.n_coded_blocks * 128 + WIDTH * HEIGHT * 3)  # 128 B/block in + 3 B/pixel out
     mean_ms = float(np.mean(kern_ms))

@@ -65,6 +65,19 @@ int fail(jb_ctx *ctx, int code, const char *fmt, ...) {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Makes the context's device current for the duration of a call and restores the caller's
+// (a jb_ctx may live on any GPU of the node; the calling thread may be using another one).
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
 int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
   int rc = jb_geometry_of(d, g);
   if (rc == JB_ERR_NULL) return fail(ctx, rc, "null descriptor");
@@ -143,7 +156,8 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   // device rows are padded to 16 B (kernel fast path needs 4-B aligned rows): <= 15 B per row
   ctx->rgb_alloc = max_rgb_bytes ? max_rgb_bytes + 16u * 65536u : 0;
   ctx->n_slots = max_coef_bytes ? n_slots : 0;
-  hipError_t e = hipSetDevice(device_id);
+  DeviceGuard guard(device_id);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
     Slot &s = ctx->slots[i];
@@ -164,7 +178,7 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
 
 void jb_ctx_destroy(jb_ctx *ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 8; i++) {
     Slot &s = ctx->slots[i];
@@ -184,6 +198,7 @@ void *jb_ctx_stream(jb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int jb_ctx_synchronize(jb_ctx *ctx) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_synchronize: ctx is NULL");
+  DeviceGuard guard(ctx->device);
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return JB_OK;
 }
@@ -223,6 +238,7 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   p.n_tiles = (int32_t)n_tiles;
   p.fast_store = (((uintptr_t)b->d_rgb & 3) == 0 && (b->rgb_row_stride & 3) == 0 && (b->rgb_image_stride & 3) == 0) ? 1 : 0;
   p.chroma_q_equal = (b->desc.qtab_id[1] == b->desc.qtab_id[2]) ? 1 : 0;
+  DeviceGuard guard(ctx->device);
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   JB_HIP(ctx, jbk_launch(p, b->desc.hs, b->desc.vs, s));
   return JB_OK;
@@ -255,7 +271,7 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
   if ((size_t)g.coef_bytes > ctx->max_coef || (size_t)(dev_stride * desc->height) > ctx->rgb_alloc ||
       (size_t)g.rgb_bytes > ctx->max_rgb)
     return fail(ctx, JB_ERR_CAPACITY, "image %dx%d exceeds the capacity the context was created with", desc->width, desc->height);
-  JB_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   Slot &s = ctx->slots[ctx->next_slot];
   if (s.busy) {  // ring full: wait for the oldest submission
     JB_HIP(ctx, hipEventSynchronize(s.done));
@@ -291,6 +307,7 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
 
 int jb_wait(jb_ctx *ctx, int ticket) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_wait: ctx is NULL");
+  DeviceGuard guard(ctx->device);
   for (int i = 0; i < ctx->n_slots; i++) {
     Slot &s = ctx->slots[i];
     if (s.ticket == ticket) {
