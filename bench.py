@@ -180,7 +180,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                # the PMC passes profile the default command: only report them for that workload
+                if rec.get("algorithmic_bytes_per_launch") in (None, alg_bytes):
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
