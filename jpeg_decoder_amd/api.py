@@ -63,9 +63,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(_LIB_PATH) and not os.environ.get("JPEGBLK_LIB"):
+        # not built yet (fresh checkout): compile it -- building is not a fallback, there is none
+        try:
+            build_library()
+        except Exception as e:  # hipcc missing, compile error ...
+            raise ImportError(f"{_LIB_PATH} is missing and could not be built ({e}); run "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the block pipeline)") from e
     if not os.path.exists(_LIB_PATH):
-        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(there is no CPU fallback for the block pipeline)")
+        raise ImportError(f"{_LIB_PATH} is missing (there is no CPU fallback for the block pipeline)")
     # PyTorch bundles its own HIP/HSA runtime with the same sonames as /opt/rocm's; two copies
     # in one process cannot both open the GPU.  Load torch's first (when torch is present) so
     # that libjpegblk.so binds to the runtime torch tensors and streams live in.
