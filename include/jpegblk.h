@@ -156,6 +156,13 @@ const char *jb_kernel_name(const jb_image_desc *desc);
  * (progressive SOF2, != 3 components, chroma not 1x1, luma factors outside {1,2}). */
 int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                       uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes);
+/* The same with the restart intervals of ONE image (DRI; e.g. the reference's images/img4.jpg)
+ * decoded by n_threads host threads: intervals are independent because the DC predictors reset
+ * at every restart (reference jpeg.cpp:419-425).  Images without restart markers, or with
+ * markers that do not match the frame, take the serial path.  Output is identical. */
+int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
+                         uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes,
+                         int n_threads);
 /* decode(path) -> RGB: the reference's whole `Image(path); readJPEG();` surface
  * (jpeg.cpp:797-807, 826-907) minus the X11 sink.  *rgb is malloc'd (tight rows, width*3);
  * release it with jb_free(). */

@@ -106,6 +106,7 @@ def lib():
     L.jb_kernel_name.argtypes = [pd]
     L.jb_kernel_name.restype = ctypes.c_char_p
     L.jb_entropy_decode.argtypes = [vp, ctypes.c_size_t, pd, vp, vp, ctypes.c_size_t]
+    L.jb_entropy_decode_mt.argtypes = [vp, ctypes.c_size_t, pd, vp, vp, ctypes.c_size_t, ctypes.c_int]
     L.jb_decode_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.jb_decode_memory.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.jb_decode_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
@@ -156,8 +157,9 @@ def resolve_qtabs(desc, qtabs):
     return out
 
 
-def entropy_decode(jpeg_bytes, headers_only=False):
-    """Host front end: JFIF bytes -> (desc, qtabs uint16 [4,64], coef int16 [n,64] or None)."""
+def entropy_decode(jpeg_bytes, headers_only=False, n_threads=1):
+    """Host front end: JFIF bytes -> (desc, qtabs uint16 [4,64], coef int16 [n,64] or None).
+    n_threads > 1 decodes the restart intervals of the image in parallel."""
     buf = np.frombuffer(jpeg_bytes, dtype=np.uint8)
     desc = ImageDesc()
     q = np.zeros((4, 64), np.uint16)
@@ -166,7 +168,7 @@ def entropy_decode(jpeg_bytes, headers_only=False):
         return desc, q, None
     g = geometry_of(desc)
     coef = np.zeros((g.n_coded_blocks, 64), np.int16)
-    _check(lib().jb_entropy_decode(_ptr(buf), buf.size, ctypes.byref(desc), _ptr(q), _ptr(coef), coef.nbytes))
+    _check(lib().jb_entropy_decode_mt(_ptr(buf), buf.size, ctypes.byref(desc), _ptr(q), _ptr(coef), coef.nbytes, n_threads))
     return desc, q, coef
 
 

@@ -91,8 +91,8 @@ struct Lane {
   }
 };
 
-void worker(Lane *lane, int t, int n_threads, const char *const *paths, int n_paths, uint8_t **rgb,
-            int32_t *widths, int32_t *heights, int *statuses, Totals *tot) {
+void worker(Lane *lane, int t, int n_threads, int inner_threads, const char *const *paths, int n_paths,
+            uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses, Totals *tot) {
   double t_entropy = 0, t_device = 0, t_read = 0;
   // pass 1: read + parse headers of this thread's files (sizes the context once)
   std::vector<int> mine;
@@ -142,7 +142,9 @@ void worker(Lane *lane, int t, int n_threads, const char *const *paths, int n_pa
     int ticket = -1;
     if (st == JB_OK) {
       double a = now_s();
-      st = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, coef[k % kSlots], max_coef);
+      // fewer files than host threads: the spare threads split each image's restart intervals
+      st = jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, coef[k % kSlots], max_coef,
+                                inner_threads);
       t_entropy += now_s() - a;
     }
     if (st == JB_OK) {
@@ -234,11 +236,13 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
   if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
   int n_threads = (int)d->lanes.size();
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
+  const int inner_threads = n_threads > 0 ? (int)d->lanes.size() / n_threads : 1;
   Totals tot;
   const double t0 = now_s();
   std::vector<std::thread> th;
   for (int t = 0; t < n_threads; t++)
-    th.emplace_back(worker, &d->lanes[(size_t)t], t, n_threads, paths, n_paths, rgb, widths, heights, statuses, &tot);
+    th.emplace_back(worker, &d->lanes[(size_t)t], t, n_threads, inner_threads, paths, n_paths, rgb, widths, heights,
+                    statuses, &tot);
   for (auto &x : th) x.join();
   if (times) {
     times[0] = now_s() - t0;

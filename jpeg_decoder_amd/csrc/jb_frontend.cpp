@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jpegblk.h"
@@ -399,6 +400,70 @@ int decode_scan(const Frame &fr, const jb_geometry &g, int16_t *coef, Err &e) {
   return JB_OK;
 }
 
+// One restart interval on its own: MCUs [m0, m1) from the bytes [b, e) that lie between two RSTn
+// markers.  DC predictors start at 0 at every restart (T.81 F.2.1.3.1; reference jpeg.cpp:419-425),
+// so intervals are independent.
+int decode_interval(const Frame &fr, const jb_geometry &g, const uint8_t *b, const uint8_t *e_, int64_t m0,
+                    int64_t m1, int16_t *coef) {
+  BitReader br(b, e_);
+  int pred[3] = {0, 0, 0};
+  const int ny = fr.desc.hs * fr.desc.vs;
+  int16_t *out = coef + m0 * g.blocks_per_mcu * 64;
+  for (int64_t m = m0; m < m1; m++)
+    for (int blk = 0; blk < ny + 2; blk++) {
+      const int c = blk < ny ? 0 : blk - ny + 1;
+      if (!decode_block(br, fr.dc[fr.dc_id[c]], fr.ac[fr.ac_id[c]], pred[c], out)) return JB_ERR_FORMAT;
+      out += 64;
+    }
+  return br.overran() ? JB_ERR_FORMAT : JB_OK;
+}
+
+// Restart intervals decoded by n_threads host threads.  Falls back to the serial decoder (which
+// produces the precise error) whenever the markers found do not match the frame.
+int decode_scan_mt(const Frame &fr, const jb_geometry &g, int16_t *coef, int n_threads, Err &e) {
+  const int64_t n_mcus = (int64_t)g.mcus_x * g.mcus_y;
+  const int ri = fr.restart_interval;
+  if (n_threads <= 1 || ri <= 0 || n_mcus <= ri) return decode_scan(fr, g, coef, e);
+  const int64_t n_int = (n_mcus + ri - 1) / ri;
+  // split the entropy-coded segment at its RSTn markers (FF D0..D7; FF 00 is a stuffed byte)
+  std::vector<const uint8_t *> start, stop;
+  const uint8_t *p = fr.scan, *end = fr.scan + fr.scan_len;
+  start.push_back(p);
+  while (p + 1 < end) {
+    if (p[0] != 0xff) {
+      p++;
+      continue;
+    }
+    const uint8_t m = p[1];
+    if (m == 0x00 || m == 0xff) {
+      p += (m == 0x00) ? 2 : 1;
+    } else if (m >= 0xd0 && m <= 0xd7) {
+      stop.push_back(p);
+      p += 2;
+      start.push_back(p);
+    } else {
+      break;  // EOI or any other marker ends the scan
+    }
+  }
+  stop.push_back(p < end ? p : end);
+  if ((int64_t)start.size() != n_int) return decode_scan(fr, g, coef, e);
+  if (n_threads > n_int) n_threads = (int)n_int;
+  std::vector<int> rcs((size_t)n_threads, JB_OK);
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back([&, t] {
+      const int64_t i0 = n_int * t / n_threads, i1 = n_int * (t + 1) / n_threads;
+      for (int64_t i = i0; i < i1 && rcs[(size_t)t] == JB_OK; i++) {
+        const int64_t m0 = i * ri, m1 = (m0 + ri < n_mcus) ? m0 + ri : n_mcus;
+        rcs[(size_t)t] = decode_interval(fr, g, start[(size_t)i], stop[(size_t)i], m0, m1, coef);
+      }
+    });
+  for (auto &x : th) x.join();
+  for (int rc : rcs)
+    if (rc != JB_OK) return set_err(e, rc, "corrupt entropy-coded data");
+  return JB_OK;
+}
+
 int report(jb_ctx *ctx, const Err &e) { return jb_fail_(ctx, e.code, e.msg.c_str()); }
 
 }  // namespace
@@ -407,6 +472,11 @@ extern "C" {
 
 int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc, uint16_t *qtabs,
                       int16_t *coef, size_t coef_cap_bytes) {
+  return jb_entropy_decode_mt(jpeg, jpeg_bytes, desc, qtabs, coef, coef_cap_bytes, 1);
+}
+
+int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc, uint16_t *qtabs,
+                         int16_t *coef, size_t coef_cap_bytes, int n_threads) {
   if (!jpeg || !desc) return jb_fail_(nullptr, JB_ERR_NULL, "jb_entropy_decode: NULL pointer");
   Frame *fr = new Frame();
   Err e;
@@ -419,7 +489,7 @@ int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *des
       rc = jb_geometry_of(&fr->desc, &g);
       if (rc) set_err(e, rc, "bad frame geometry");
       else if ((size_t)g.coef_bytes > coef_cap_bytes) rc = set_err(e, JB_ERR_CAPACITY, "coefficient buffer too small");
-      else rc = decode_scan(*fr, g, coef, e);
+      else rc = decode_scan_mt(*fr, g, coef, n_threads, e);
     }
   }
   delete fr;

@@ -186,3 +186,32 @@ def test_front_end_sixteen_bit_quant_table(jb):
     zz5 = 2  # zig-zag position 5 is natural index 2
     want[0, zz5] += 256
     assert np.array_equal(q, want) and np.array_equal(c, c0)
+
+
+def test_front_end_parallel_restart_intervals(jb):
+    """jb_entropy_decode_mt: restart intervals of one image on several threads == serial decode
+    (bundled img4.jpg: DRI = 100; PIL files: short intervals, ragged last interval); images
+    without DRI and corrupt streams take the serial path and give the same answers/errors."""
+    data = open(os.path.join(GOLD, "images", "img4.jpg"), "rb").read()
+    _, coef, _, _ = load_golden("img4")
+    for t in (2, 3, 8, 64):
+        d, q, c = jb.entropy_decode(data, n_threads=t)
+        assert np.array_equal(c, coef), t
+    d, q, c = jb.entropy_decode(open(os.path.join(GOLD, "images", "img.jpg"), "rb").read(), n_threads=8)
+    assert np.array_equal(c, load_golden("img")[1])  # no DRI: serial path
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(5)
+    img = np.clip(np.cumsum(rng.normal(0, 4, (131, 259, 3)), axis=1) + 128, 0, 255).astype(np.uint8)
+    for sub in (0, 2):
+        for blocks in (1, 3, 16):
+            f = _pil_jpeg(img, quality=80, subsampling=sub, restart_marker_blocks=blocks)
+            _, _, c1 = jb.entropy_decode(f)
+            for t in (2, 5):
+                _, _, ct = jb.entropy_decode(f, n_threads=t)
+                assert np.array_equal(ct, c1), (sub, blocks, t)
+    # a damaged interval is still reported
+    dmg = bytearray(_pil_jpeg(img, quality=80, subsampling=0, restart_marker_blocks=3))
+    sos = dmg.index(b"\xff\xda")
+    dmg[sos + 40:sos + 60] = b"\xff\xd9" * 10
+    with pytest.raises(jb.JbError):
+        jb.entropy_decode(bytes(dmg), n_threads=4)
