@@ -289,9 +289,6 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   const q_const_t *qsrc = (const q_const_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
 
   // ---- stage 2: this lane's block -> registers ----
-  const int comp = LM::comp(tid);
-  const int mcu = LM::mcu(tid);    // MCU within the tile
-  const int slot = LM::slot(tid);  // luma block within the MCU
   const int comp_a = LM::comp(wave * 64);       // first lane's component (wave-uniform)
   const int comp_b = LM::comp(wave * 64 + 63);  // last lane's component
   const q_const_t *qa = qsrc + comp_a * 64;
@@ -362,7 +359,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         }
       }
     } else {
-      const bool second = comp == comp_b;
+      const bool second = LM::comp(tid) == comp_b;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
 #pragma unroll
@@ -408,13 +405,18 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   // bv; chroma blocks contribute rows 4*phase..4*phase+3 (chroma row r covers luma rows 2r, 2r+1).
   // A strip row is a sequence of 16-B chunks (4 samples); chunk c is stored at position
   // c ^ ((c>>3)&1) so that the 8 lanes of a ds_write_b128 group hit 8 different bank quads.
-  const int bv = comp == 0 ? slot / HS : 0;
-  const int bh = comp == 0 ? slot - bv * HS : 0;
-  const int pitch = comp == 0 ? (YW * 4) : CW * 4;
-  const int blk_col = comp == 0 ? mcu * HS + bh : mcu;  // 8-sample column of the block in its strip
+  // (everything per-lane here is derived from an opaque copy of the thread id, so that it is
+  // materialised after the IDCT instead of occupying registers across it)
+  int tid_late = tid;
+  asm volatile("" : "+v"(tid_late));
+  const int comp_l = LM::comp(tid_late), mcu_l = LM::mcu(tid_late), slot_l = LM::slot(tid_late);
+  const int bv = comp_l == 0 ? slot_l / HS : 0;
+  const int bh = comp_l == 0 ? slot_l - bv * HS : 0;
+  const int pitch = comp_l == 0 ? (YW * 4) : CW * 4;
+  const int blk_col = comp_l == 0 ? mcu_l * HS + bh : mcu_l;  // 8-sample column of the block in its strip
   const int sw = (blk_col >> 2) & 1;
   const int luma_off = bv * 4 * (YW * 4) + blk_col * 32;
-  char *const dst = lds + (comp == 0 ? luma_off : (comp == 1 ? CB_OFF : CR_OFF) + blk_col * 32);
+  char *const dst = lds + (comp_l == 0 ? luma_off : (comp_l == 1 ? CB_OFF : CR_OFF) + blk_col * 32);
   char *const dst_lo = dst + sw * 16;        // samples 0..3 of a row
   char *const dst_hi = dst + (sw ^ 1) * 16;  // samples 4..7
 
@@ -429,8 +431,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   // (the swizzle bit is bit 3 of the chunk index, which the segment number does not touch)
   // (computed from an opaque copy of the lane id so they are materialised here, after the IDCT,
   // instead of being kept in registers across it)
-  int lane_late = lane;
-  asm volatile("" : "+v"(lane_late));
+  const int lane_late = tid_late & 63;
   const int lane_y_off = (lane_late ^ ((lane_late >> 3) & 1)) * 16;
   const int lane_c_off = HS == 1 ? lane_y_off : (((lane_late >> 1) ^ ((lane_late >> 4) & 1)) * 16 + (lane_late & 1) * 8);
 
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
         *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
       }
-    } else if (comp == 0) {
+    } else if (comp_l == 0) {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const int k = phase * 4 + kk;
