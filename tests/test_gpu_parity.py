@@ -175,7 +175,7 @@ def test_unaligned_output_slow_path(jb, oracle):
     assert np.array_equal(got, oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q))
 
 
-@pytest.mark.parametrize("w,h,hs,vs", [(4096, 4096, 1, 1), (4096, 4096, 2, 2), (1920, 1080, 1, 1)])
+@pytest.mark.parametrize("w,h,hs,vs", [(4096, 4096, 1, 1), (4096, 4096, 2, 2), (1920, 1080, 1, 1), (8192, 8192, 2, 2)])
 def test_full_size_configs_vs_oracle_and_properties(jb, oracle, w, h, hs, vs):
     """BASELINE.json's single-GPU configurations at full size: bit-exact against the
     (multi-threaded) oracle, plus two size-independent properties of the path:
@@ -279,3 +279,28 @@ def test_decode_pil_files_all_layouts_with_restarts(jb, big_ctx, oracle, tmp_pat
             # sanity: the picture is recognisably the input (the reference's IDCT is not the
             # encoder's inverse to the last bit, so only a loose bound)
             assert np.abs(got.astype(int) - img.astype(int)).mean() < 8
+
+
+def test_batch_of_1080p_images_one_launch(jb, oracle):
+    """BASELINE config 4 shape (a GPU's share of a batch of 1920x1080 4:4:4 images) through the
+    batched device entry point: every image of the launch against the oracle."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    w, h, nimg = 1920, 1080, 6
+    desc = jb.make_desc(w, h, 1, 1)
+    coefs = [synth.synth_blocks(w, h, 1, 1, i)[0] for i in range(nimg)]
+    q = synth.annex_k_qtabs(90)
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(dev)
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(np.stack(coefs)).to(dev)
+        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+        rgb_t = torch.zeros((nimg, h, 3 * w), dtype=torch.uint8, device=dev)
+        ctx.blocks_to_rgb_device(torch_batch(desc, nimg, coef_t, q_t, rgb_t), ts.cuda_stream)
+        torch.cuda.synchronize()
+    got = rgb_t.cpu().numpy()
+    for i in range(nimg):
+        want = oracle.blocks_to_rgb(odesc(w, h, 1, 1), coefs[i], q, nthreads=16)
+        assert np.array_equal(got[i].reshape(h, w, 3), want), i
