@@ -233,7 +233,15 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   p.mcus_x = g.mcus_x;
   p.mcus_y = g.mcus_y;
   p.tiles_per_row = (g.mcus_x + per_tile - 1) / per_tile;
-  const int64_t n_tiles = (int64_t)b->n_images * g.mcus_y * p.tiles_per_row;
+  // JPEGBLK_ROW_TILING=1 (debug / A-B knob) forces the row-bound tiling
+  static const bool force_row = getenv("JPEGBLK_ROW_TILING") && getenv("JPEGBLK_ROW_TILING")[0] == '1';
+  // linear tiling only where the row-bound one would leave ragged tiles
+  p.linear = (force_row || g.mcus_x % per_tile == 0) ? 0 : jbk_linear_ok(b->desc.hs, b->desc.vs, g.mcus_x);
+  const int64_t tiles_per_image = p.linear ? ((int64_t)g.mcus_x * g.mcus_y + per_tile - 1) / per_tile
+                                           : (int64_t)g.mcus_y * p.tiles_per_row;
+  if (tiles_per_image > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "image too large");
+  p.tiles_per_image = (int32_t)tiles_per_image;
+  const int64_t n_tiles = (int64_t)b->n_images * tiles_per_image;
   if (n_tiles > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "batch too large for one launch (%lld tiles)", (long long)n_tiles);
   p.n_tiles = (int32_t)n_tiles;
   p.fast_store = (((uintptr_t)b->d_rgb & 3) == 0 && (b->rgb_row_stride & 3) == 0 && (b->rgb_image_stride & 3) == 0) ? 1 : 0;

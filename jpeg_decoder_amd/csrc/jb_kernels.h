@@ -15,16 +15,19 @@ struct JbLaunch {
   int64_t rgb_row_stride;     // bytes
   int32_t width, height;      // pixels
   int32_t mcus_x, mcus_y;     // coded MCUs per row / column
-  int32_t tiles_per_row;      // ceil(mcus_x / jbk_mcus_per_tile(hs, vs))
-  int32_t n_tiles;            // n_images * mcus_y * tiles_per_row = workgroups launched
+  int32_t tiles_per_row;      // row-bound tiling: ceil(mcus_x / jbk_mcus_per_tile(hs, vs))
+  int32_t tiles_per_image;    // linear: ceil(mcus_x*mcus_y / per_tile); row-bound: tiles_per_row*mcus_y
+  int32_t n_tiles;            // n_images * tiles_per_image = workgroups launched
+  int32_t linear;             // 1 = tiles follow the MCU stream, 0 = tiles are runs of one MCU row
   int32_t fast_store;         // 1 when rgb base and every stride are multiples of 4 bytes
   int32_t chroma_q_equal;     // 1 when Cb and Cr use the same table (desc.qtab_id[1] == qtab_id[2])
   int32_t reserved;           // 0 (777 = skip switch of the timing-experiment builds)
-  int32_t pad_;
 };
 
 // MCUs covered by one workgroup (a tile is always 192 coded blocks): 64 / 48 / 32.
 int jbk_mcus_per_tile(int hs, int vs);
+// Can the layout use the linear (MCU-stream) tiling for an image with mcus_x MCUs per row?
+int jbk_linear_ok(int hs, int vs, int mcus_x);
 // Launch the fused kernel for luma sampling (hs, vs): one 192-lane workgroup per tile.
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream);
 const char *jbk_kernel_name(int hs, int vs);

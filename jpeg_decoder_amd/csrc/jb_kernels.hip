@@ -245,9 +245,9 @@ struct LaneMap {
 // same table, the usual case).  MIXQ = true: a wave may hold blocks of two components with
 // different tables and selects per lane; kept out of the MIXQ = false instantiation because its
 // register pressure would cost the common case a wave per SIMD.
-template <int HS, int VS, bool MIXQ>
+template <int HS, int VS, bool MIXQ, bool LINEAR>
 // (forcing 5 waves/SIMD on the 4:2:0 instantiation spills 7 registers and measured 9 % slower)
-__global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
+__global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_kernel(const JbLaunch p) {
   using LM = LaneMap<HS, VS>;
   constexpr int NB = LM::NB, MCUS = LM::MCUS, NYT = LM::NYT;
   constexpr int YW = MCUS * 8 * HS;             // luma strip width in pixels
@@ -264,10 +264,7 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- which tile (all wave-uniform) ----
-  const int tiles_per_image = p.tiles_per_row * p.mcus_y;
-#ifdef JB_NO_XCD_REMAP
-  const int tile = blockIdx.x;
-#else
+  const int tiles_per_image = p.tiles_per_image;
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
   // XCD, each with its own L2), so give every XCD one contiguous band of tiles: its L2 then holds
   // whole image rows of dirty lines and whole runs of coefficient bytes, instead of every 8th
@@ -277,12 +274,23 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
     const int nwg = p.n_tiles, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
-#endif
   const int img = tile / tiles_per_image;
   const int rem = tile - img * tiles_per_image;
-  const int my = rem / p.tiles_per_row;
-  const int mx0 = (rem - my * p.tiles_per_row) * MCUS;
-  const int nvalid = min(MCUS, p.mcus_x - mx0);
+  // Two tilings.  Linear (p.linear, the default): a tile is 192/NB consecutive MCUs of the image's
+  // MCU stream, whatever MCU rows they fall in -- every tile but the image's last is full for any
+  // image width.  Row-bound: a tile is a run of MCUs of ONE MCU row (the last run of a row may be
+  // short); used for very narrow images and for the 4:4:0 layout.
+  int my, mx0, nvalid;
+  if (LINEAR) {
+    const int m0 = rem * MCUS;
+    my = m0 / p.mcus_x;
+    mx0 = m0 - my * p.mcus_x;
+    nvalid = min(MCUS, p.mcus_x * p.mcus_y - m0);
+  } else {
+    my = rem / p.tiles_per_row;
+    mx0 = (rem - my * p.tiles_per_row) * MCUS;
+    nvalid = min(MCUS, p.mcus_x - mx0);
+  }
   const int last_block = nvalid * NB - 1;
   const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride +
                              ((int64_t)my * p.mcus_x + mx0) * (NB * 128);
@@ -478,9 +486,21 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
         // invariant offset lane*12 and the hardware range check drops lanes past the image edge).
         constexpr int IPR = TASKS_PER_ROW / 64;  // wave-iterations per strip row
         const int row = it / IPR, seg = it - row * IPR;
-        const int y = y_base + (row >> 2) * 8 + (row & 3);
-        const int x_seg = tile_x0 + seg * 256;  // first pixel of this wave-iteration
-        if (y >= p.height || x_seg >= p.width) continue;
+        // where the segment's 256 pixels (SEG_MCUS MCUs) go: MCU row my_s from MCU column mx_s on;
+        // in the linear tiling the segment may run past the end of the MCU row and continue at
+        // the start of the next one (at most once: the host only selects the linear tiling when
+        // an MCU row holds at least one whole segment)
+        constexpr int SEG_MCUS = 256 / (8 * HS);
+        const int seg_valid = min(SEG_MCUS, nvalid - seg * SEG_MCUS);  // MCUs of the segment that exist
+        if (seg_valid <= 0) continue;
+        int my_s = my, mx_s = mx0 + seg * SEG_MCUS;
+        if (LINEAR)
+          while (mx_s >= p.mcus_x) {
+            mx_s -= p.mcus_x;
+            my_s++;
+          }
+        const int n_row = min(seg_valid, p.mcus_x - mx_s);  // MCUs before the wrap
+        const int y_in = phase * 4 + (row >> 2) * 8 + (row & 3);  // pixel row within the MCU row
         const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
         float cb[4], cr[4];
         // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
@@ -509,30 +529,42 @@ __global__ __launch_bounds__(192) void jb_tile_kernel(const JbLaunch p) {
           }
         }
         if (!JB_DO_STORE(p)) continue;
-        uint8_t *const segp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x_seg * 3;
-        const int px_left = min(256, p.width - x_seg);  // pixels of this segment inside the image
-        if (p.fast_store) {
-          uint32_t w0, w1, w2;
-          pack12_rtz(r, g, b, w0, w1, w2);
-          // whole 4-pixel groups only: a group straddling the image edge is left to the tail below
-          const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (px_left >> 2) * 12, 0x00020000);
-          __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, lane_late * 12, 0, JB_STORE_AUX);
-        }
-        if (!p.fast_store || (px_left & 3)) {
-          // unaligned output, or the one group that straddles the right edge: byte stores
-          const int first = p.fast_store ? (px_left & ~3) : 0;
-          int lane_tail = lane_late;  // opaque copy: keeps this rare path's address arithmetic
-          asm volatile("" : "+v"(lane_tail));  // from being hoisted out of the loop into registers
+        uint32_t w0 = 0, w1 = 0, w2 = 0;
+        if (p.fast_store) pack12_rtz(r, g, b, w0, w1, w2);
+        // part 0: the MCUs before the wrap; part 1 (linear tiling only): the rest, one MCU row down
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int px = lane_tail * 4 + i;
-            if (px >= first && px < px_left) {
-              uint8_t *o = segp + px * 3;
-              o[0] = (uint8_t)pack_u8(r[i], 0, 0);
-              o[1] = (uint8_t)pack_u8(g[i], 0, 0);
-              o[2] = (uint8_t)pack_u8(b[i], 0, 0);
+        for (int part = 0; part < (LINEAR ? 2 : 1); part++) {
+          const int px0 = part == 0 ? 0 : n_row * 8 * HS;  // first segment pixel of the part
+          const int y = (my_s + part) * 8 * VS + y_in;
+          const int x0 = part == 0 ? mx_s * 8 * HS : 0;     // image column of that pixel
+          const int npx = min((part == 0 ? n_row : seg_valid - n_row) * 8 * HS, p.width - x0);
+          if (npx > 0 && y < p.height) {
+            uint8_t *const segp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x0 * 3;  // address of pixel px0
+            const int rel = lane_late * 4 - px0;  // this lane's first pixel relative to the part
+            if (p.fast_store && (part == 0 || rel >= 0)) {
+              // whole 4-pixel groups only (a group straddling the image edge is left to the tail
+              // below); the descriptor's range check drops the lanes past the part's end
+              const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (npx >> 2) * 12, 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, rel * 3, 0, JB_STORE_AUX);
+            }
+            if (!p.fast_store || (npx & 3)) {
+              // unaligned output, or the one group that straddles the right edge: byte stores
+              const int first = p.fast_store ? (npx & ~3) : 0;
+              int rel_tail = rel;  // opaque copy: keeps this rare path's address arithmetic
+              asm volatile("" : "+v"(rel_tail));  // from being hoisted out of the loop into registers
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const int px = rel_tail + i;
+                if (px >= first && px < npx) {
+                  uint8_t *o = segp + px * 3;
+                  o[0] = (uint8_t)pack_u8(r[i], 0, 0);
+                  o[1] = (uint8_t)pack_u8(g[i], 0, 0);
+                  o[2] = (uint8_t)pack_u8(b[i], 0, 0);
+                }
+              }
             }
           }
+          if (!LINEAR || n_row >= seg_valid) break;  // no second part
         }
       } else {
         const int t = it * 64 + lane;
@@ -592,14 +624,31 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   constexpr bool kLumaChromaMixed = (LM::NYT % 64 != 0);                      // 4:2:2, 4:4:0
   constexpr bool kCbCrMixed = (LM::MCUS % 64 != 0);                           // all but 4:4:4
   const bool mixq = kLumaChromaMixed || (kCbCrMixed && !p.chroma_q_equal);
-  if (mixq)
-    hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
-  else
-    hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false>), dim3(p.n_tiles), dim3(kTileBlocks), 0, stream, p);
+  // the linear tiling is a separate instantiation: where the row-bound tiling leaves no tile
+  // ragged (mcus_x a multiple of the tile length, e.g. 4096- and 8192-pixel rows) the simpler
+  // row-bound code is 2 % faster
+  constexpr bool kCanLinear = ((LM::MCUS * 8 * HS / 4) % 64 == 0);
+  const dim3 grid(p.n_tiles), block(kTileBlocks);
+  if (kCanLinear && p.linear) {
+    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, 0, stream, p);
+  } else {
+    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, false>), grid, block, 0, stream, p);
+  }
   return hipGetLastError();
 }
 
 int jbk_mcus_per_tile(int hs, int vs) { return kTileBlocks / (hs * vs + 2); }
+
+// The linear tiling needs the colour stage's row-uniform path (a 256-pixel segment of a strip row
+// is one wave-iteration: 4:4:4, 4:2:2, 4:2:0) and MCU rows at least one segment long, so that a
+// segment wraps to the next MCU row at most once.
+int jbk_linear_ok(int hs, int vs, int mcus_x) {
+  const int strip_tasks_per_row = jbk_mcus_per_tile(hs, vs) * 8 * hs / 4;
+  if (strip_tasks_per_row % 64 != 0) return 0;  // 4:4:0
+  return mcus_x >= 256 / (8 * hs);
+}
 
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
@@ -611,8 +660,9 @@ hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
 }
 
 const char *jbk_kernel_name(int hs, int vs) {
-  if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1, false>";
-  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1, true>";
-  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2, true>";
-  return "jb_tile_kernel<2, 2, false>";  // <2, 2, true> when Cb and Cr use different tables
+  // <HS, VS, MIXQ, LINEAR>: the last two depend on the tables and the image width
+  if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1, false, *>";
+  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1, true, *>";
+  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2, true, false>";
+  return "jb_tile_kernel<2, 2, *, *>";
 }
