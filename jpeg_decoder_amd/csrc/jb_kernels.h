@@ -19,7 +19,7 @@ struct JbLaunch {
   int32_t tiles_per_image;    // linear: ceil(mcus_x*mcus_y / per_tile); row-bound: tiles_per_row*mcus_y
   int32_t n_tiles;            // n_images * tiles_per_image = workgroups launched
   int32_t linear;             // 1 = tiles follow the MCU stream, 0 = tiles are runs of one MCU row
-  int32_t fast_store;         // 1 when rgb base and every stride are multiples of 4 bytes
+  int32_t fast_store;         // 1: 12-byte stores (any byte alignment); 0: byte stores (JPEGBLK_BYTE_STORE=1)
   int32_t chroma_q_equal;     // 1 when Cb and Cr use the same table (desc.qtab_id[1] == qtab_id[2])
   int32_t reserved;           // 0 (777 = skip switch of the timing-experiment builds)
 };

@@ -5,10 +5,16 @@
 // coefficient once and writes every pixel once.
 //
 // Work decomposition (wave64, no MFMA -- this is 8-point butterflies, not a GEMM):
-//   * a workgroup (3 waves, 192 lanes) owns one TILE = a run of 192/NB consecutive MCUs of one
-//     MCU row (NB = hs*vs + 2 coded blocks per MCU): 64 MCUs in 4:4:4, 32 in 4:2:0, 48 in
+//   * a workgroup (3 waves, 192 lanes) owns one TILE = a run of 192/NB consecutive MCUs
+//     (NB = hs*vs + 2 coded blocks per MCU): 64 MCUs in 4:4:4, 32 in 4:2:0, 48 in
 //     4:2:2 / 4:4:0 -- always 192 coded blocks = 24 KiB of contiguous int16 coefficients in.
-//     blockIdx -> tile is XCD-aware (each XCD gets one contiguous band of tiles).
+//     Two tilings, chosen by the host (jb_api.cpp) and compiled as separate instantiations:
+//       row-bound (LINEAR=false): tiles never cross an MCU row; the last tile of a row is
+//         partly empty unless mcus_x is a multiple of the tile length (4096/8192 px are);
+//       linear (LINEAR=true): tiles cut the image's MCU stream every 192/NB MCUs regardless of
+//         rows, so only the last tile of an image can be short; a colour segment may then
+//         straddle one row end and is stored in two parts (1920 px: +4.2 %).
+//     blockIdx -> tile is the identity (one compact advancing write window; XCD bands were slower).
 //   * stage 1+2, one lane = one coded 8x8 block.  Lanes take the tile's blocks sorted by
 //     component, so the quantisation table is wave-uniform (scalar loads -> SGPRs) wherever
 //     possible (4:4:4: wave w = component w).  The lane's 128 coefficient bytes reach 32 VGPRs
@@ -76,6 +82,9 @@ __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(f
 #endif
 #ifndef JB_STORE_AUX
 #define JB_STORE_AUX 2
+#endif
+#ifndef JB_SCHED_FENCE
+#define JB_SCHED_FENCE() ((void)0)
 #endif
 constexpr int kTileBlocks = 192;                  // coded blocks per tile = lanes per workgroup
 constexpr int kStripBytes = kTileBlocks * 128;    // 24 KiB: half of the tile's f32 samples
@@ -265,15 +274,22 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
 
   // ---- which tile (all wave-uniform) ----
   const int tiles_per_image = p.tiles_per_image;
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
-  // XCD, each with its own L2), so give every XCD one contiguous band of tiles: its L2 then holds
-  // whole image rows of dirty lines and whole runs of coefficient bytes, instead of every 8th
-  // 1.5 KiB piece.  Bijective for any grid size.  Placement only affects speed, never results.
+  // blockIdx -> tile is the identity: workgroups are dealt round-robin over the 8 XCDs, so at any
+  // moment the resident workgroups of ALL XCDs write one compact, advancing window of the output.
+  // The "XCD-aware" alternative (every XCD owns one contiguous band of tiles, so that its L2 holds
+  // whole rows) was measured and is slower: neutral on 4:4:4, -3.5 % on 4:2:0 (write-heavy), -1 %
+  // elsewhere -- nothing is re-read, so there is no L2 locality to win, and eight separate write
+  // windows cost HBM page locality (tools/probe_store2.hip: the same 403 MB written by one
+  // advancing window reach 6.4 TB/s, by many separate streams 5.2 TB/s).
   int tile;
+#ifdef JB_EXPERIMENT_XCD_BANDS  // measured 1-3.5 % slower (see the comment above): not the default
   {
     const int nwg = p.n_tiles, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
+#else
+  tile = blockIdx.x;
+#endif
   const int img = tile / tiles_per_image;
   const int rem = tile - img * tiles_per_image;
   // Two tilings.  Linear (p.linear, the default): a tile is 192/NB consecutive MCUs of the image's
@@ -394,17 +410,17 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
       aan_1d_io(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
                 v[6 * 8 + i], v[7 * 8 + i],  //
                 v[0 * 8 + i], v[1 * 8 + i], v[4 * 8 + i], v[5 * 8 + i], v[2 * 8 + i], v[3 * 8 + i],
-                v[6 * 8 + i], v[7 * 8 + i]);
+                v[6 * 8 + i], v[7 * 8 + i]), JB_SCHED_FENCE();
   } else {
 #pragma unroll
     for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
       aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i],
-             v[6 * 8 + i], v[7 * 8 + i]);
+             v[6 * 8 + i], v[7 * 8 + i]), JB_SCHED_FENCE();
   }
 #pragma unroll
   for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
-           v[k * 8 + 6], v[k * 8 + 7]);
+           v[k * 8 + 6], v[k * 8 + 7]), JB_SCHED_FENCE();
   }
 
   // ---- stage 3: two phases (upper / lower half of the tile's pixel rows) ----
@@ -501,6 +517,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
           }
         const int n_row = min(seg_valid, p.mcus_x - mx_s);  // MCUs before the wrap
         const int y_in = phase * 4 + (row >> 2) * 8 + (row & 3);  // pixel row within the MCU row
+        if (!LINEAR && (my * 8 * VS + y_in >= p.height || mx_s * 8 * HS >= p.width)) continue;
         const float4 Y = *(const float4 *)(lds + lane_y_off + row * (YW * 4) + seg * 1024);
         float cb[4], cr[4];
         // chroma sample of luma pixel (row, col): (row/VS, col/HS) -- reference jpeg.cpp:518-520
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
         }
         if (!JB_DO_STORE(p)) continue;
         uint32_t w0 = 0, w1 = 0, w2 = 0;
-        if (p.fast_store) pack12_rtz(r, g, b, w0, w1, w2);
+        if (LINEAR && p.fast_store) pack12_rtz(r, g, b, w0, w1, w2);  // once for both parts
         // part 0: the MCUs before the wrap; part 1 (linear tiling only): the rest, one MCU row down
 #pragma unroll
         for (int part = 0; part < (LINEAR ? 2 : 1); part++) {
@@ -544,17 +561,20 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
             if (p.fast_store && (part == 0 || rel >= 0)) {
               // whole 4-pixel groups only (a group straddling the image edge is left to the tail
               // below); the descriptor's range check drops the lanes past the part's end
+              if (!LINEAR) pack12_rtz(r, g, b, w0, w1, w2);
               const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (npx >> 2) * 12, 0x00020000);
-              __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, rel * 3, 0, JB_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, LINEAR ? rel * 3 : lane_late * 12, 0, JB_STORE_AUX);
             }
             if (!p.fast_store || (npx & 3)) {
               // unaligned output, or the one group that straddles the right edge: byte stores
               const int first = p.fast_store ? (npx & ~3) : 0;
-              int rel_tail = rel;  // opaque copy: keeps this rare path's address arithmetic
-              asm volatile("" : "+v"(rel_tail));  // from being hoisted out of the loop into registers
+              // opaque copy of a value that is live anyway: keeps this rare path's address
+              // arithmetic from being hoisted out of the loop into registers
+              int tail_src = LINEAR ? rel : lane_late;
+              asm volatile("" : "+v"(tail_src));
 #pragma unroll
               for (int i = 0; i < 4; i++) {
-                const int px = rel_tail + i;
+                const int px = (LINEAR ? tail_src : tail_src * 4) + i;
                 if (px >= first && px < npx) {
                   uint8_t *o = segp + px * 3;
                   o[0] = (uint8_t)pack_u8(r[i], 0, 0);

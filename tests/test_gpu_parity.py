@@ -151,28 +151,39 @@ def test_device_batch_api_per_image_tables(jb, oracle):
     assert g.n_coded_blocks == coefs[0].shape[0]
 
 
-def test_unaligned_output_slow_path(jb, oracle):
-    """rgb pointer / stride not multiples of 4 -> the byte-store path of the kernel."""
+@pytest.mark.parametrize("byte_store", [False, True])
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_unaligned_output_both_store_paths(jb, oracle, monkeypatch, hs, vs, byte_store):
+    """rgb pointer / stride not multiples of 4 (odd widths with tightly packed rows are the common
+    case): the default path stores 12 bytes per lane at byte-aligned addresses, JPEGBLK_BYTE_STORE=1
+    selects the byte-store path.  Both must be exact and must not touch a byte outside the rows."""
     import torch
     from jpeg_decoder_amd import synth
     from jpeg_decoder_amd.api import torch_batch
     from oracle.pyoracle import make_desc as odesc
-    w, h = 333, 41
-    desc = jb.make_desc(w, h, 1, 1)
-    coef, q = synth.synth_blocks(w, h, 1, 1, 9)
+    if byte_store:
+        monkeypatch.setenv("JPEGBLK_BYTE_STORE", "1")
+    else:
+        monkeypatch.delenv("JPEGBLK_BYTE_STORE", raising=False)
     dev = torch.device("cuda:0")
     ts = torch.cuda.Stream(dev)
-    stride = 3 * w + 2
-    with torch.cuda.stream(ts), jb.Context(0) as ctx:
-        coef_t = torch.from_numpy(coef).to(dev)
-        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
-        raw = torch.zeros(h * stride + 8, dtype=torch.uint8, device=dev)
-        view = raw[1:1 + h * stride].view(1, h, stride)
-        b = torch_batch(desc, 1, coef_t.view(1, -1, 64), q_t, view)
-        ctx.blocks_to_rgb_device(b, ts.cuda_stream)
-        torch.cuda.synchronize()
-    got = view.cpu().numpy()[0, :, :3 * w].reshape(h, w, 3)
-    assert np.array_equal(got, oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q))
+    for (w, h, pad, off) in [(333, 41, 2, 1), (679, 451, 0, 3), (1921, 37, 1, 2), (515, 16, 0, 1)]:
+        desc = jb.make_desc(w, h, hs, vs)
+        coef, q = synth.synth_blocks(w, h, hs, vs, 9)
+        stride = 3 * w + pad
+        with torch.cuda.stream(ts), jb.Context(0) as ctx:
+            coef_t = torch.from_numpy(coef).to(dev)
+            q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+            raw = torch.full((h * stride + 16,), 0xC5, dtype=torch.uint8, device=dev)
+            view = raw[off:off + h * stride].view(1, h, stride)
+            b = torch_batch(desc, 1, coef_t.view(1, -1, 64), q_t, view)
+            ctx.blocks_to_rgb_device(b, ts.cuda_stream)
+            torch.cuda.synchronize()
+        host = raw.cpu().numpy()
+        rows = host[off:off + h * stride].reshape(h, stride)
+        want = oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=4)
+        assert np.array_equal(rows[:, :3 * w].reshape(h, w, 3), want), (w, h, hs, vs, byte_store)
+        assert (rows[:, 3 * w:] == 0xC5).all() and (host[:off] == 0xC5).all() and (host[off + h * stride:] == 0xC5).all()
 
 
 @pytest.mark.parametrize("w,h,hs,vs", [(4096, 4096, 1, 1), (4096, 4096, 2, 2), (1920, 1080, 1, 1), (8192, 8192, 2, 2)])

@@ -1,0 +1,23 @@
+#!/bin/bash
+# A/B of library builds on ONE GPU box, interleaved so that box-to-box and power-state drift
+# cancel:  bash tools/ab_bench.sh "<lib A> <lib B> ..." "<workload[:images]> ..." [reps]
+# Each library is a path to a libjpegblk.so build (JPEGBLK_LIB picks it up, api.py).
+set -u
+LIBS=${1:?libs}
+WLS=${2:-"4096x4096-444 1920x1080-444:128 4096x4096-420"}
+REPS=${3:-3}
+for rep in $(seq $REPS); do
+  for w in $WLS; do
+    wl=${w%%:*}; n=8; [[ $w == *:* ]] && n=${w##*:}
+    for lib in $LIBS; do
+      JPEGBLK_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --workload $wl --images-per-step $n 2>/dev/null |
+        python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']
+        print('%-28s %-22s kernel %.1f us (min %.1f)  %.0f GB/s  frac %.3f' % ('$(basename $lib)', '$wl x$n', r['kernel_ms_mean'] * 1e3, r['kernel_ms_min'] * 1e3, r['achieved'], r['frac']))
+"
+    done
+  done
+done
