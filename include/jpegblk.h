@@ -195,6 +195,13 @@ void jb_batch_decoder_destroy(jb_batch_decoder *dec);
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,
                  int64_t rgb_stride);
+/* Replaces Image::saveToBMP / writeBMP (jpeg.cpp:462-509, 809-816): an uncompressed 24-bit
+ * Windows BMP (BITMAPINFOHEADER, bottom-up rows padded to 4 bytes, bytes in B,G,R order).  The
+ * reference writes the 12-byte OS/2 core header (16-bit sizes) and puts the planes out as
+ * R,B,G (jpeg.cpp:497-499) with a padding of width%4 bytes (jpeg.cpp:472), which viewers show
+ * with swapped colours or skewed rows; this writer emits what viewers expect. */
+int jb_write_bmp(const char *path, const uint8_t *rgb, int32_t width, int32_t height,
+                 int64_t rgb_stride);
 
 #ifdef __cplusplus
 }

@@ -73,8 +73,14 @@ class Image {
   // mcus[(y/8)*mcuWidthReal + x/8].{r,g,b}[(y%8)*8 + x%8] of the reference (display.hpp:19-34).
   const uint8_t *rgb() const { return rgb_; }
 
-  // reference: saveToBMP(string), jpeg.cpp:809-816 (never called from its main, and it writes
-  // R,B,G order -- jpeg.cpp:497-499).  The sink here is a binary PPM.
+  // reference: saveToBMP(string), jpeg.cpp:809-816 (never called from its main; its writer puts
+  // the planes out in R,B,G order behind an OS/2 core header -- jpeg.cpp:462-509).  Same name,
+  // standard 24-bit BMP.
+  void saveToBMP(const std::string &filename) const {
+    int rc = jb_write_bmp(filename.c_str(), rgb_, image_width, image_height, 3LL * image_width);
+    if (rc) throw Error(rc, jb_last_error(nullptr));
+  }
+  // binary PPM (P6): the sink used in place of the reference's X11 window (display.hpp)
   void savePPM(const std::string &filename) const {
     int rc = jb_write_ppm(filename.c_str(), rgb_, image_width, image_height, 3LL * image_width);
     if (rc) throw Error(rc, jb_last_error(nullptr));

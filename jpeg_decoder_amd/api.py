@@ -119,6 +119,7 @@ def lib():
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
+    L.jb_write_bmp.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
     if L.jb_abi_version() != 1:
         raise ImportError("libjpegblk.so ABI version mismatch")
     _lib = L

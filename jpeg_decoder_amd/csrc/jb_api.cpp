@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/jpegblk.h"
 #include "jb_kernels.h"
@@ -357,6 +358,41 @@ int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t he
     }
   fclose(f);
   return JB_OK;
+}
+
+int jb_write_bmp(const char *path, const uint8_t *rgb, int32_t width, int32_t height, int64_t rgb_stride) {
+  if (!path || !rgb) return fail(nullptr, JB_ERR_NULL, "jb_write_bmp: NULL pointer");
+  if (width < 1 || height < 1 || rgb_stride < 3LL * width) return fail(nullptr, JB_ERR_GEOMETRY, "jb_write_bmp: bad geometry");
+  const int64_t row_bytes = (3LL * width + 3) & ~3LL;  // rows are padded to 4 bytes
+  const int64_t file_bytes = 54 + row_bytes * height;
+  if (file_bytes > 0xffffffffLL) return fail(nullptr, JB_ERR_CAPACITY, "jb_write_bmp: %dx%d exceeds the 4 GiB BMP limit", width, height);
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(nullptr, JB_ERR_FORMAT, "cannot open %s for writing", path);
+  uint8_t hdr[54] = {'B', 'M'};
+  auto le32 = [&](int at, uint32_t v) { for (int i = 0; i < 4; i++) hdr[at + i] = (uint8_t)(v >> (8 * i)); };
+  le32(2, (uint32_t)file_bytes);
+  le32(10, 54);                    // offset of the pixel array
+  le32(14, 40);                    // BITMAPINFOHEADER
+  le32(18, (uint32_t)width);
+  le32(22, (uint32_t)height);      // positive: bottom-up
+  hdr[26] = 1;                     // planes
+  hdr[28] = 24;                    // bits per pixel; compression 0 (BI_RGB)
+  le32(34, (uint32_t)(row_bytes * height));
+  le32(38, 2835);                  // 72 dpi
+  le32(42, 2835);
+  bool ok = fwrite(hdr, 1, sizeof hdr, f) == sizeof hdr;
+  std::vector<uint8_t> row((size_t)row_bytes, 0);
+  for (int y = height - 1; ok && y >= 0; y--) {
+    const uint8_t *src = rgb + (int64_t)y * rgb_stride;
+    for (int x = 0; x < width; x++) {
+      row[3 * x + 0] = src[3 * x + 2];
+      row[3 * x + 1] = src[3 * x + 1];
+      row[3 * x + 2] = src[3 * x + 0];
+    }
+    ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+  }
+  if (fclose(f) != 0) ok = false;
+  return ok ? JB_OK : fail(nullptr, JB_ERR_FORMAT, "short write to %s", path);
 }
 
 }  // extern "C"

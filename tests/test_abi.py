@@ -131,6 +131,24 @@ def test_write_ppm(jb, tmp_path):
     assert raw.startswith(b"P6\n5 3\n255\n") and raw[len(b"P6\n5 3\n255\n"):] == rgb.tobytes()
 
 
+@pytest.mark.parametrize("w,h", [(5, 3), (4, 4), (7, 2), (1, 1), (333, 17)])
+def test_write_bmp_reads_back(jb, tmp_path, w, h):
+    """saveToBMP replacement (reference jpeg.cpp:462-509 writes R,B,G behind an OS/2 header): the
+    file must read back, in a standard reader, as exactly the RGB buffer -- with row padding and a
+    source stride larger than the row."""
+    from PIL import Image
+    rng = np.random.default_rng(w * 100 + h)
+    stride = 3 * w + 5
+    buf = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    p = tmp_path / "o.bmp"
+    assert jb.lib().jb_write_bmp(str(p).encode(), buf.ctypes.data, w, h, stride) == 0
+    assert p.stat().st_size == 54 + ((3 * w + 3) // 4 * 4) * h
+    got = np.asarray(Image.open(p).convert("RGB"))
+    assert np.array_equal(got, buf[:, :3 * w].reshape(h, w, 3))
+    assert jb.lib().jb_write_bmp(str(p).encode(), buf.ctypes.data, w, h, 3 * w - 1) == -2
+    assert jb.lib().jb_write_bmp(None, buf.ctypes.data, w, h, stride) == -1
+
+
 def _pil_jpeg(img, **kw):
     import io
     from PIL import Image

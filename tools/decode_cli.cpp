@@ -2,19 +2,24 @@
 // display();) against this library: decode(path) -> RGB, written as a PPM instead of an X11 window.
 //   g++ -std=c++17 -Iinclude tools/decode_cli.cpp -Ljpeg_decoder_amd -ljpegblk -Wl,-rpath,$PWD/jpeg_decoder_amd -o tools/decode_cli
 #include <cstdio>
+#include <string>
 
 #include "jpegblk.hpp"
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "Usage : %s <filename.jpg> [out.ppm]\n", argv[0]);
+    fprintf(stderr, "Usage : %s <filename.jpg> [out.ppm|out.bmp]\n", argv[0]);
     return 1;
   }
   try {
     jpegblk::Image jpeg(argv[1]);
     jpeg.readJPEG();
     printf("%s: %dx%d\n", argv[1], jpeg.image_width, jpeg.image_height);
-    if (argc > 2) jpeg.savePPM(argv[2]);
+    if (argc > 2) {
+      const std::string out = argv[2];
+      if (out.size() > 4 && out.compare(out.size() - 4, 4, ".bmp") == 0) jpeg.saveToBMP(out);
+      else jpeg.savePPM(out);
+    }
   } catch (const jpegblk::Error &e) {
     fprintf(stderr, "-> ERROR: %s (status %d)\n", e.what(), e.status);
     return 1;
