@@ -191,6 +191,13 @@ int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
 int jb_batch_decoder_run(jb_batch_decoder *dec, const char *const *paths, int n_paths, uint8_t **rgb,
                          int32_t *widths, int32_t *heights, int *statuses, double *times);
 void jb_batch_decoder_destroy(jb_batch_decoder *dec);
+/* Optional pinned output arena owned by the decoder (bytes = 0 releases it).  With an arena,
+ * jb_batch_decoder_run places every decoded image in it -- rgb[i] points INTO the arena: do not
+ * jb_free it; it stays valid until the next run, set_arena or destroy -- and the device writes the
+ * pixels straight to their final place: no per-image allocation, no host copy.  An image that
+ * does not fit fails with JB_ERR_CAPACITY.  Without an arena the pixels go through per-thread
+ * pinned staging and are copied into malloc'ed buffers (release with jb_free). */
+int jb_batch_decoder_set_arena(jb_batch_decoder *dec, size_t bytes);
 /* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,

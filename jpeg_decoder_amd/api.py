@@ -116,6 +116,7 @@ def lib():
     L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
+    L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
@@ -244,16 +245,32 @@ class Context:
             lib().jb_free(p)
         return arr.reshape(h.value, w.value, 3)
 
+    def decode_memory(self, jpeg_bytes):
+        """jb_decode_memory: a JFIF byte string -> RGB [H, W, 3] (front end + device seam)."""
+        buf = np.frombuffer(jpeg_bytes, dtype=np.uint8)
+        p, w, h = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32()
+        _check(lib().jb_decode_memory(self._h, _ptr(buf), buf.size, ctypes.byref(p), ctypes.byref(w), ctypes.byref(h)), self._h)
+        try:
+            n = w.value * h.value * 3
+            arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
+        finally:
+            lib().jb_free(p)
+        return arr.reshape(h.value, w.value, 3)
+
 
 class BatchDecoder:
     """jb_batch_decoder: n_threads host lanes (context + pinned buffers each), reusable."""
 
-    def __init__(self, n_threads=8, device=0, max_coef_bytes=0, max_rgb_bytes=0):
+    def __init__(self, n_threads=8, device=0, max_coef_bytes=0, max_rgb_bytes=0, arena_bytes=0):
         self._h = ctypes.c_void_p()
         _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
+        self._arena = False
+        if arena_bytes:
+            _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))
+            self._arena = True
 
     def run(self, paths, keep_pixels=True):
-        return decode_batch(paths, keep_pixels=keep_pixels, _decoder=self._h)
+        return decode_batch(paths, keep_pixels=keep_pixels, _decoder=self._h, _arena=self._arena)
 
     def close(self):
         if self._h:
@@ -267,7 +284,7 @@ class BatchDecoder:
         self.close()
 
 
-def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None):
+def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None, _arena=False):
     """jb_decode_batch: -> (list of uint8 [H,W,3] arrays or None, statuses, times dict)."""
     n = len(paths)
     arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
@@ -289,7 +306,8 @@ def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None):
                 out.append(a.reshape(h[i], w[i], 3))
             else:
                 out.append((w[i], h[i]))
-            lib().jb_free(rgb[i])
+            if not _arena:  # arena images belong to the decoder
+                lib().jb_free(rgb[i])
         else:
             out.append(None)
     t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc}

@@ -233,3 +233,75 @@ def test_front_end_parallel_restart_intervals(jb):
     dmg[sos + 40:sos + 60] = b"\xff\xd9" * 10
     with pytest.raises(jb.JbError):
         jb.entropy_decode(bytes(dmg), n_threads=4)
+
+
+# ---- stream-level round trips through the build's own baseline writer (tools/jpegwriter) ----
+
+def test_annex_k_huffman_tables_match_libjpeg():
+    """The writer's Huffman tables (synth.ANNEX_K_HUFFMAN, ITU-T T.81 Annex K.3) are the ones a
+    libjpeg-written file carries in its DHT segments."""
+    pytest.importorskip("PIL")
+    from jpeg_decoder_amd import synth
+    raw = _pil_jpeg(np.zeros((16, 16, 3), np.uint8), quality=90)
+    tabs, i = {}, 2
+    while raw[i + 1] != 0xDA:
+        length = raw[i + 2] * 256 + raw[i + 3]
+        if raw[i + 1] == 0xC4:
+            seg, j = raw[i + 4:i + 2 + length], 0
+            while j < len(seg):
+                n = sum(seg[j + 1:j + 17])
+                tabs[(seg[j] >> 4, seg[j] & 15)] = (list(seg[j + 1:j + 17]), list(seg[j + 17:j + 17 + n]))
+                j += 17 + n
+        i += 2 + length
+    for key, (bits, vals) in zip([(0, 0), (1, 0), (0, 1), (1, 1)], synth.ANNEX_K_HUFFMAN):
+        assert tabs[key] == (list(bits), list(vals)), key
+
+
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_writer_round_trip_blocks_exact(jb, hs, vs):
+    """blocks -> baseline stream -> jb_entropy_decode -> the same blocks, tables and geometry:
+    ragged sizes, restart intervals of any length (1 MCU, not dividing the row, longer than the
+    image), 8- and 16-bit DQT, separate chroma tables, serial and restart-parallel decoding."""
+    from jpeg_decoder_amd import synth
+    q = synth.annex_k_qtabs(75)
+    q[2] = np.clip(q[1].astype(int) + 3, 1, 255)
+    cases = [(1, 1, 0), (8, 8, 0), (17, 33, 1), (100, 60, 3), (333, 211, 7), (640, 360, 40), (515, 300, 100000 % 65536),
+             (1920, 1080, 0)]
+    for i, (w, h, ri) in enumerate(cases):
+        qid = (0, 1, 2) if i % 2 else (0, 1, 1)
+        coef, _ = synth.synth_blocks(w, h, hs, vs, i, qtabs=q, qtab_id=qid)
+        for dqt16 in (False, True):
+            data = synth.encode_jpeg(coef, w, h, hs, vs, q, qid, restart_interval=ri, dqt16=dqt16)
+            assert data[:2] == b"\xff\xd8" and data[-2:] == b"\xff\xd9"
+            for threads in (1, 4):
+                desc, q2, c2 = jb.entropy_decode(data, n_threads=threads)
+                assert (desc.width, desc.height, desc.hs, desc.vs, tuple(desc.qtab_id)) == (w, h, hs, vs, qid)
+                assert np.array_equal(c2, coef), (w, h, ri, dqt16, threads)
+                for t in set(qid):
+                    assert np.array_equal(q2[t], q[t])
+
+
+def test_writer_round_trip_extreme_values(jb):
+    """Largest magnitudes the baseline alphabet can carry (DC difference +-2047, AC +-1023), long
+    zero runs (ZRL), blocks that end exactly at coefficient 63 (no EOB), and 16-bit table entries."""
+    from jpeg_decoder_amd import synth
+    w, h = 64, 48
+    n = synth.geometry(w, h, 1, 1)[3]
+    rng = np.random.default_rng(5)
+    coef = np.zeros((n, 64), np.int16)
+    coef[:, 0] = np.where(np.arange(n) % 2, 1023, -1024)           # DC differences of +-2047
+    coef[::3, 63] = rng.choice([-1023, 1023, 1, -1], size=len(coef[::3]))   # run of 62 zeros, no EOB
+    coef[1::3, 17] = -1023
+    coef[1::3, 40] = 512
+    coef[2::3, 1:] = rng.integers(-1023, 1024, size=(len(coef[2::3]), 63))  # dense
+    q = np.zeros((4, 64), np.uint16)
+    q[0] = 1
+    q[1] = np.arange(1, 65) * 1000 % 65535 + 1   # 16-bit entries
+    data = synth.encode_jpeg(coef, w, h, 1, 1, q, (0, 1, 1), dqt16=True)
+    desc, q2, c2 = jb.entropy_decode(data)
+    assert np.array_equal(c2, coef) and np.array_equal(q2[:2], q[:2])
+    with pytest.raises(ValueError):           # 8-bit DQT cannot hold those entries
+        synth.encode_jpeg(coef, w, h, 1, 1, q, (0, 1, 1), dqt16=False)
+    coef[5, 9] = 1024                          # outside the baseline AC alphabet
+    with pytest.raises(ValueError):
+        synth.encode_jpeg(coef, w, h, 1, 1, q, (0, 1, 1), dqt16=True)

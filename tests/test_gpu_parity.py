@@ -315,3 +315,45 @@ def test_batch_of_1080p_images_one_launch(jb, oracle):
     for i in range(nimg):
         want = oracle.blocks_to_rgb(odesc(w, h, 1, 1), coefs[i], q, nthreads=16)
         assert np.array_equal(got[i].reshape(h, w, 3), want), i
+
+
+@pytest.mark.parametrize("w,h,hs,vs,ri", [(1920, 1080, 1, 1, 0), (4096, 4096, 2, 2, 256), (8192, 8192, 2, 2, 0),
+                                           (679, 451, 2, 2, 5), (1000, 700, 2, 1, 0), (1000, 700, 1, 2, 63)])
+def test_stream_round_trip_full_sizes(jb, oracle, w, h, hs, vs, ri):
+    """decode(bytes) at BASELINE's sizes (configs 2, 3, 5) with the build's own baseline writer:
+    blocks -> JFIF stream -> jb_decode_memory (host Huffman + device seam) must equal the oracle
+    on the blocks that were written -- the whole surface, no fixture size limit."""
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    coef, q = synth.synth_blocks(w, h, hs, vs, 77)
+    data = synth.encode_jpeg(coef, w, h, hs, vs, q, restart_interval=ri)
+    desc = jb.make_desc(w, h, hs, vs)
+    with jb.Context.for_image(desc, 0, n_slots=1) as ctx:
+        got = ctx.decode_memory(data)
+    want = oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=16)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_batch_decoder_output_arena(jb, tmp_path):
+    """jb_batch_decoder_set_arena: images land in the decoder's pinned arena (no per-image
+    allocation or host copy); same pixels as the default malloc path; an arena that is too small
+    fails the images that do not fit with JB_ERR_CAPACITY and decodes the rest."""
+    import ctypes
+    names = BASELINE_IMAGES * 2
+    paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
+    want = [load_golden(n)[3] for n in names]
+    total = sum((w.size + 255) // 256 * 256 for w in want)
+    with jb.BatchDecoder(3, 0, arena_bytes=total) as dec:
+        for _ in range(2):      # the arena is recycled by every run
+            imgs, st, tm = dec.run(paths)
+            assert tm["rc"] == 0 and all(x == 0 for x in st)
+            for got, w in zip(imgs, want):
+                assert np.array_equal(got, w)
+    small = total - 256
+    with jb.BatchDecoder(2, 0, arena_bytes=small) as dec:
+        imgs, st, tm = dec.run(paths)
+        assert tm["rc"] == -5 and sorted(set(st)) == [-5, 0] and st.count(-5) >= 1
+        for got, w, x in zip(imgs, want, st):
+            assert (got is None) if x else np.array_equal(got, w)
+    imgs, st, tm = jb.decode_batch(paths, n_threads=3)      # default path, for comparison
+    assert tm["rc"] == 0 and all(np.array_equal(g, w) for g, w in zip(imgs, want))

@@ -96,3 +96,24 @@ def test_oracle_matches_reference_on_random_blocks(oracle, hs, vs):
         n = oracle.geometry(d).n_coded_blocks
         for coef in (synth.random_blocks(n, seed), synth.random_blocks(n, seed + 10, -64, 64)):
             assert np.array_equal(oracle.blocks_to_rgb(d, coef, q), ref.blocks_to_rgb(d, coef, q))
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h,hs,vs,rows", [(679, 451, 2, 2, 0), (333, 211, 1, 1, 0), (100, 60, 2, 1, 0),
+                                              (64, 80, 1, 2, 0), (640, 360, 1, 1, 2), (512, 256, 2, 2, 1)])
+def test_writer_streams_through_the_reference_reader(oracle, tmp_path, w, h, hs, vs, rows):
+    """Pins the build's baseline writer (tools/jpegwriter) with the genuine reference: the
+    reference's own marker parser + Huffman decoder (oracle/_ref) must read back exactly the
+    blocks and tables that were written, and its RGB must equal the oracle's on them.  Restart
+    intervals only as whole MCU rows -- the reference's restart test (jpeg.cpp:414,419) counts
+    block rows, see INTEGRATION.md section 5."""
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import Ref, make_desc
+    coef, q = synth.synth_blocks(w, h, hs, vs, 21)
+    ri = rows * synth.geometry(w, h, hs, vs)[0]
+    p = tmp_path / "w.jpg"
+    p.write_bytes(synth.encode_jpeg(coef, w, h, hs, vs, q, restart_interval=ri))
+    info, rcoef, rq, rrgb = Ref().decode_file(str(p))
+    assert (info.width, info.height, info.hs, info.vs) == (w, h, hs, vs)
+    assert np.array_equal(rcoef, coef) and np.array_equal(rq[:2], q[:2])
+    assert np.array_equal(rrgb, oracle.blocks_to_rgb(make_desc(w, h, hs, vs), coef, q))

@@ -5,7 +5,12 @@
       optimisation -- the kind of file the reference's front end accepts);
   (2) PCIe-inclusive block pipeline: pre-decoded coefficient blocks in pinned host memory ->
       jb_submit/jb_wait ring -> pixels in pinned host memory (no Huffman).
+Every decode(path) line also carries the device-busy fraction (kernel time of the images decoded /
+wall time; the kernel time is measured on a resident copy of one image), i.e. how idle the GPU is
+while the host Huffman stage is the bottleneck.
 Usage: python tools/e2e_bench.py [--size 1920x1080] [--sub 444|420] [--n 256] [--threads 1,8,16,64]
+                                 [--source pil|writer]
+  --source writer: files from the build's own baseline writer (tools/jpegwriter) on synthetic blocks
 """
 import argparse
 import ctypes
@@ -36,6 +41,41 @@ def make_jpegs(n_distinct, w, h, sub, out_dir):
     return paths
 
 
+def make_jpegs_writer(n_distinct, w, h, sub, out_dir):
+    from jpeg_decoder_amd import synth
+    hs, vs = {"444": (1, 1), "420": (2, 2), "422": (2, 1), "440": (1, 2)}[sub]
+    paths = []
+    for i in range(n_distinct):
+        coef, q = synth.synth_blocks(w, h, hs, vs, i)
+        p = os.path.join(out_dir, f"writer_{w}x{h}_{sub}_{i}.jpg")
+        with open(p, "wb") as f:
+            f.write(synth.encode_jpeg(coef, w, h, hs, vs, q))
+        paths.append(p)
+    return paths
+
+
+def kernel_ms_per_image(desc, q, coef):
+    """Device time of one image's launch with the blocks resident in HBM (torch = plumbing)."""
+    import torch
+    from jpeg_decoder_amd.api import torch_batch
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(dev)
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
+        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+        rgb_t = torch.empty((1, desc.height, 3 * desc.width), dtype=torch.uint8, device=dev)
+        b = torch_batch(desc, 1, coef_t, q_t, rgb_t)
+        for _ in range(50):
+            ctx.blocks_to_rgb_device(b, ts.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ts)
+        for _ in range(50):
+            ctx.blocks_to_rgb_device(b, ts.cuda_stream)
+        e1.record(ts)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 50
+
+
 def pinned_array(nbytes, dtype):
     p = jb.lib().jb_pinned_alloc(nbytes)
     if not p:
@@ -50,27 +90,38 @@ def main():
     ap.add_argument("--sub", default="444")
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--threads", default="1,8,16,32,64")
+    ap.add_argument("--source", default="pil", choices=["pil", "writer"])
+    ap.add_argument("--distinct", type=int, default=8)
+    ap.add_argument("--modes", default="malloc,arena")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
-    out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count()}
+    out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count(),
+           "cpu_affinity": len(os.sched_getaffinity(0)), "source": args.source}
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        distinct = make_jpegs(8, w, h, args.sub, d)
+        distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d)
         paths = [distinct[i % len(distinct)] for i in range(args.n)]
         out["file_kbytes_mean"] = round(float(np.mean([os.path.getsize(p) for p in distinct])) / 1024, 1)
         # warm-up (file cache, HIP init)
         jb.decode_batch(paths[:8], n_threads=4, keep_pixels=False)
         res = []
-        d0, _, _ = jb.entropy_decode(open(distinct[0], "rb").read(), headers_only=True)
+        d0, q0, c0 = jb.entropy_decode(open(distinct[0], "rb").read())
         g0 = jb.geometry_of(d0)
-        for t in [int(x) for x in args.threads.split(",")]:
-            with jb.BatchDecoder(t, 0, g0.coef_bytes, g0.rgb_bytes) as dec:
+        k_ms = kernel_ms_per_image(d0, q0, c0)
+        out["kernel_ms_per_image"] = round(k_ms, 4)
+        del c0
+        # two output modes: "malloc" = the default ABI (pixels copied from pinned staging into
+        # malloc'ed per-image buffers), "arena" = a pinned output arena owned by the decoder
+        for mode, t in [(m, int(x)) for m in args.modes.split(",") for x in args.threads.split(",")]:
+            arena = (args.n * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
+            with jb.BatchDecoder(t, 0, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
                 dec.run(paths[:t], keep_pixels=False)          # touch every lane once
                 _, st, tm = dec.run(paths, keep_pixels=False)  # timed: contexts and pinned buffers exist
             assert all(s == 0 for s in st), st[:8]
-            res.append({"threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
+            res.append({"output": mode, "threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
                         "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
                         "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
-                        "wall_s": round(tm["wall_s"], 3)})
+                        "wall_s": round(tm["wall_s"], 3),
+                        "device_busy_fraction": round(args.n * k_ms * 1e-3 / tm["wall_s"], 4)})
         out["decode_path"] = res
         # (2) PCIe-inclusive block pipeline from pre-decoded coefficients
         desc, q, coef = jb.entropy_decode(open(distinct[0], "rb").read())
