@@ -50,6 +50,27 @@ __global__ __launch_bounds__(192) void mix_tile(const uint8_t *in, uint8_t *out,
   if (threadIdx.x == 100000) dyn[0] = 1;
 }
 
+// 4:2:0 shape: 192 threads, 24 KiB read, 24 KiB written as 16 rows x 1536 B (1:2 read:write mix)
+__global__ __launch_bounds__(192) void mix_tile420(const uint8_t *in, uint8_t *out, long pitch, int tiles_per_row) {
+  extern __shared__ char dyn[];
+  const int t = blockIdx.x;
+  const uint8_t *src = in + (long)t * 24576 + threadIdx.x * 128;
+  u4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = *(const u4 *)(src + i * 16);
+  const int ty = t / tiles_per_row, tx = t - ty * tiles_per_row;
+  uint8_t *base = out + (long)ty * 16 * pitch + (long)tx * 1536;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u4 acc = v[0] ^ v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7];
+  int k = 0;
+  for (int it = wave; it < 32; it += 3, k++) {
+    const int row = it >> 1, seg = it & 1;
+    u3 w = u3{acc.x + k, acc.y, acc.z ^ acc.w};
+    __builtin_nontemporal_store(w, (u3 *)(base + (long)row * pitch + seg * 768 + lane * 12));
+  }
+  if (threadIdx.x == 100000) dyn[0] = 1;
+}
+
 int main() {
   const long rbytes = 8L * 4096 * 4096 * 6, wbytes = rbytes / 2;
   uint8_t *din, *dout;
@@ -92,5 +113,26 @@ int main() {
   time("tile pattern, nt stores, 24 KiB LDS (6 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 24576>>>(din, dout, 12288, 8); });
   time("tile pattern, nt stores, 40 KiB LDS (4 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 40960>>>(din, dout, 12288, 8); });
   time("tile pattern, nt stores, 64 KiB LDS (2 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 65536>>>(din, dout, 12288, 8); });
+  {  // 4:2:0 batch: 8 x 4096^2: 402.7 MB read + 402.7 MB written
+    const long r420 = 8L * 4096 * 4096 * 3;
+    const int nt420 = r420 / 24576;
+    auto time420 = [&](const char *name, auto launch) {
+      float best = 1e9, sum = 0;
+      int n = 0;
+      for (int rep = 0; rep < 300; rep++) {
+        (void)hipEventRecord(e0);
+        launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 200) { sum += ms; n++; if (ms < best) best = ms; }
+      }
+      printf("%-52s mean %.1f us  min %.1f us  %.2f TB/s\n", name, sum / n * 1e3, best * 1e3, 2.0 * r420 / (sum / n * 1e-3) / 1e12);
+    };
+    time420("4:2:0 mix (1:2), tile pattern, nt stores", [&] { mix_tile420<<<nt420, 192>>>(din, dout, 12288, 8); });
+    time420("4:2:0 mix, 24 KiB LDS (6 WG/CU)", [&] { mix_tile420<<<nt420, 192, 24576>>>(din, dout, 12288, 8); });
+    time420("4:2:0 mix, 40 KiB LDS (4 WG/CU)", [&] { mix_tile420<<<nt420, 192, 40960>>>(din, dout, 12288, 8); });
+  }
   return 0;
 }
