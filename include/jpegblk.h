@@ -36,7 +36,7 @@
  * OWNERSHIP: all buffers are caller-owned; the library never frees or retains caller pointers
  * past the call (async: past jb_wait).  ERRORS: every function returns a jb_status, never
  * calls exit() (the reference logs and exit(1)s, e.g. jpeg.cpp:71-72,85-86).
- * THREADING: a jb_ctx is bound to one device and one HIP stream; calls on one ctx must be
+ * THREADING: a jb_ctx is bound to one device and its own HIP streams; calls on one ctx must be
  * serialised by the caller, different contexts may be used concurrently from different threads.
  */
 #ifndef JPEGBLK_H
@@ -97,16 +97,21 @@ int jb_device_count(void);
 int jb_geometry_of(const jb_image_desc *desc, jb_geometry *out);
 /* Create a context on `device_id` with its own stream.  `max_coef_bytes`/`max_rgb_bytes`
  * size the per-slot device and pinned staging buffers used by the host-buffer entry points
- * (0,0: device-pointer entry points only).  `n_slots` (1..8) = depth of the staging ring. */
+ * (0,0: device-pointer entry points only).  `n_slots` (1..64) = depth of the staging ring
+ * (each slot holds one image's coefficients and pixels in device memory). */
 int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, int n_slots,
                   jb_ctx **out);
 void jb_ctx_destroy(jb_ctx *ctx);
 /* Text of the last error on this context (or of the last context-less error on this thread
  * when ctx is NULL).  Never NULL. */
 const char *jb_last_error(const jb_ctx *ctx);
-/* The context's HIP stream (hipStream_t) so callers can order their own work against it. */
+/* The context's primary HIP stream (hipStream_t): what device-resident launches with a NULL
+ * stream argument run on, so callers can order their own work against them.  (The staging ring
+ * of jb_submit uploads and computes on this stream and downloads on a second one, so that the
+ * device->host copy of image i overlaps the host->device copy of image i+1; order against the
+ * downloads with jb_wait.) */
 void *jb_ctx_stream(jb_ctx *ctx);
-/* Block until everything submitted to the context's stream has finished. */
+/* Block until everything submitted to the context (either stream) has finished. */
 int jb_ctx_synchronize(jb_ctx *ctx);
 
 /* ---- the seam: host buffers (drop-in for jpeg.cpp:786-788) ----------------------------- */
@@ -116,10 +121,15 @@ int jb_blocks_to_rgb(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef
                      const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride);
 /* Asynchronous flavour over the staging ring, so the host Huffman stage of image i+1 overlaps
  * the device work of image i.  `coef`/`rgb` should come from jb_pinned_alloc for true overlap
- * and must stay valid until jb_wait(ticket) returns.  Blocks only when all slots are busy. */
+ * and must stay valid until jb_wait(ticket) returns.  Blocks only when all slots are busy.
+ * Submissions complete in order. */
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef,
               const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride, int *ticket);
 int jb_wait(jb_ctx *ctx, int ticket);
+/* Non-blocking jb_wait: JB_OK once the submission has completed, JB_PENDING (> 0, not an error)
+ * while it is still in flight. */
+#define JB_PENDING 1
+int jb_poll(jb_ctx *ctx, int ticket);
 void *jb_pinned_alloc(size_t bytes);
 void jb_pinned_free(void *p);
 

@@ -116,6 +116,7 @@ def lib():
     L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
+    L.jb_poll.argtypes = [vp, ctypes.c_int]
     L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
@@ -226,6 +227,14 @@ class Context:
         _check(lib().jb_submit(self._h, ctypes.byref(desc), _ptr(coef), _ptr(q), _ptr(out),
                                stride or 3 * desc.width, ctypes.byref(t)), self._h)
         return t.value
+
+    def poll(self, ticket):
+        """True once the submission has completed (non-blocking)."""
+        rc = lib().jb_poll(self._h, ticket)
+        if rc == 1:
+            return False
+        _check(rc, self._h)
+        return True
 
     def wait(self, ticket):
         _check(lib().jb_wait(self._h, ticket), self._h)

@@ -1,9 +1,12 @@
 // jb_api.cpp -- the C ABI of include/jpegblk.h over the HIP kernels of jb_kernels.hip.
 //
 // Host side of the seam dequantize(); inverseDCT(); YCbCrToRGB(); (reference
-// jpeg.cpp:786-788).  A jb_ctx owns one HIP stream and a ring of staging slots (device
+// jpeg.cpp:786-788).  A jb_ctx owns two HIP streams and a ring of staging slots (device
 // coefficient / pixel buffers + a pinned quant-table block each) so that the copies and the
-// kernel of image i overlap the host Huffman stage of image i+1.  There is deliberately NO CPU
+// kernel of image i overlap the host Huffman stage of image i+1.  One stream uploads and
+// computes (H2D + kernel), the other downloads (D2H, ordered after the kernel by an event), so
+// the pixels of image i travel device->host while the coefficients of image i+1 travel
+// host->device (the link is full duplex: 57 GB/s one way, 97 GB/s both ways, tools/probe_pcie.hip).  There is deliberately NO CPU
 // fallback here: without a usable HIP device every compute entry point fails with JB_ERR_HIP.
 #include <hip/hip_runtime_api.h>
 
@@ -27,7 +30,8 @@ struct Slot {
   void *d_rgb = nullptr;
   int32_t *h_q = nullptr;  // pinned int32[3][64]
   int32_t *d_q = nullptr;
-  hipEvent_t done = nullptr;
+  hipEvent_t computed = nullptr;  // kernel finished (upload stream) -> the download may start
+  hipEvent_t done = nullptr;      // pixels are in the caller's buffer
   bool busy = false;
   int ticket = -1;
 };
@@ -36,10 +40,11 @@ struct Slot {
 
 struct jb_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // primary: uploads + kernels of the ring; device-resident launches with a NULL stream
+  hipStream_t stream2 = nullptr;  // downloads of the staging ring
   size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
   int n_slots = 0;
-  Slot slots[8];
+  Slot slots[64];  // n_slots of them are in use
   int next_slot = 0;
   int next_ticket = 1;
   std::string error;
@@ -116,18 +121,21 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   if ((max_coef_bytes == 0) != (max_rgb_bytes == 0))
     return fail(nullptr, JB_ERR_CAPACITY, "max_coef_bytes and max_rgb_bytes must both be zero or both non-zero");
   if (n_slots < 1) n_slots = 1;
-  if (n_slots > 8) n_slots = 8;
+  if (n_slots > 64) n_slots = 64;
   jb_ctx *ctx = new (std::nothrow) jb_ctx();
   if (!ctx) return fail(nullptr, JB_ERR_CAPACITY, "out of host memory");
   ctx->device = device_id;
   ctx->max_coef = max_coef_bytes;
   ctx->max_rgb = max_rgb_bytes;
-  // device rows are padded to 16 B (kernel fast path needs 4-B aligned rows): <= 15 B per row
-  ctx->rgb_alloc = max_rgb_bytes ? max_rgb_bytes + 16u * 65536u : 0;
+  ctx->rgb_alloc = max_rgb_bytes ? (size_t)round_up((int64_t)max_rgb_bytes, 256) : 0;  // device rows are tightly packed
   ctx->n_slots = max_coef_bytes ? n_slots : 0;
   DeviceGuard guard(device_id);
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  // JPEGBLK_SINGLE_STREAM=1 (A/B knob): downloads on the upload stream as well
+  const char *single = getenv("JPEGBLK_SINGLE_STREAM");
+  if (e == hipSuccess && ctx->n_slots > 0 && !(single && single[0] == '1'))
+    e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
     Slot &s = ctx->slots[i];
     e = hipMalloc(&s.d_coef, round_up((int64_t)max_coef_bytes, 256));
@@ -135,6 +143,7 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
     if (e == hipSuccess) e = hipMalloc((void **)&s.d_q, 768);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_q, 768, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
   }
   if (e != hipSuccess) {
     int rc = fail(nullptr, JB_ERR_HIP, "jb_ctx_create: %s", hipGetErrorString(e));
@@ -149,15 +158,18 @@ void jb_ctx_destroy(jb_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < 8; i++) {
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  for (int i = 0; i < 64; i++) {
     Slot &s = ctx->slots[i];
     if (s.d_coef) (void)hipFree(s.d_coef);
     if (s.d_rgb) (void)hipFree(s.d_rgb);
     if (s.d_q) (void)hipFree(s.d_q);
     if (s.h_q) (void)hipHostFree(s.h_q);
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.computed) (void)hipEventDestroy(s.computed);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
 }
 
@@ -169,6 +181,7 @@ int jb_ctx_synchronize(jb_ctx *ctx) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_synchronize: ctx is NULL");
   DeviceGuard guard(ctx->device);
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   return JB_OK;
 }
 
@@ -249,9 +262,8 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
   int rc = check_desc(ctx, desc, &g);
   if (rc) return rc;
   if (rgb_stride < 3LL * desc->width) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
-  const int64_t dev_stride = round_up(3LL * desc->width, 16);
-  if ((size_t)g.coef_bytes > ctx->max_coef || (size_t)(dev_stride * desc->height) > ctx->rgb_alloc ||
-      (size_t)g.rgb_bytes > ctx->max_rgb)
+  const int64_t dev_stride = 3LL * desc->width;  // tight rows on the device (12-byte stores need no alignment)
+  if ((size_t)g.coef_bytes > ctx->max_coef || (size_t)g.rgb_bytes > ctx->rgb_alloc || (size_t)g.rgb_bytes > ctx->max_rgb)
     return fail(ctx, JB_ERR_CAPACITY, "image %dx%d exceeds the capacity the context was created with", desc->width, desc->height);
   DeviceGuard guard(ctx->device);
   Slot &s = ctx->slots[ctx->next_slot];
@@ -259,10 +271,11 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
     JB_HIP(ctx, hipEventSynchronize(s.done));
     s.busy = false;
   }
+  hipStream_t up = ctx->stream, down = ctx->stream2 ? ctx->stream2 : ctx->stream;
   rc = jb_resolve_qtabs(desc, qtabs, s.h_q);
   if (rc) return fail(ctx, rc, "bad quantisation table id");
-  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768, hipMemcpyHostToDevice, ctx->stream));
-  JB_HIP(ctx, hipMemcpyAsync(s.d_coef, coef, (size_t)g.coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768, hipMemcpyHostToDevice, up));
+  JB_HIP(ctx, hipMemcpyAsync(s.d_coef, coef, (size_t)g.coef_bytes, hipMemcpyHostToDevice, up));
   jb_device_batch b;
   memset(&b, 0, sizeof b);
   b.desc = *desc;
@@ -274,11 +287,19 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
   b.d_rgb = (uint8_t *)s.d_rgb;
   b.rgb_row_stride = dev_stride;
   b.rgb_image_stride = dev_stride * desc->height;
-  rc = jb_blocks_to_rgb_device(ctx, &b, ctx->stream);
+  rc = jb_blocks_to_rgb_device(ctx, &b, up);
   if (rc) return rc;
-  JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
-                               (size_t)desc->height, hipMemcpyDeviceToHost, ctx->stream));
-  JB_HIP(ctx, hipEventRecord(s.done, ctx->stream));
+  // the download runs on its own stream, after the kernel: it overlaps the next image's upload
+  if (down != up) {
+    JB_HIP(ctx, hipEventRecord(s.computed, up));
+    JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+  }
+  if (rgb_stride == dev_stride)
+    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, (size_t)g.rgb_bytes, hipMemcpyDeviceToHost, down));
+  else
+    JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                                 (size_t)desc->height, hipMemcpyDeviceToHost, down));
+  JB_HIP(ctx, hipEventRecord(s.done, down));
   s.busy = true;
   s.ticket = ctx->next_ticket++;
   if (ctx->next_ticket < 0) ctx->next_ticket = 1;
@@ -297,6 +318,23 @@ int jb_wait(jb_ctx *ctx, int ticket) {
         JB_HIP(ctx, hipEventSynchronize(s.done));
         s.busy = false;
       }
+      return JB_OK;
+    }
+  }
+  return fail(ctx, JB_ERR_STATE, "ticket %d is not in flight (already waited for and its slot reused?)", ticket);
+}
+
+int jb_poll(jb_ctx *ctx, int ticket) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_poll: ctx is NULL");
+  DeviceGuard guard(ctx->device);
+  for (int i = 0; i < ctx->n_slots; i++) {
+    Slot &s = ctx->slots[i];
+    if (s.ticket == ticket) {
+      if (!s.busy) return JB_OK;
+      hipError_t e = hipEventQuery(s.done);
+      if (e == hipErrorNotReady) return JB_PENDING;
+      if (e != hipSuccess) return fail(ctx, JB_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(e));
+      s.busy = false;
       return JB_OK;
     }
   }
@@ -364,6 +402,21 @@ int jb_write_bmp(const char *path, const uint8_t *rgb, int32_t width, int32_t he
 }
 
 }  // extern "C"
+
+// jb_wait in two halves for jb_batch.cpp, where many host threads share one context: the lookup
+// runs under the caller's lock, the blocking wait outside it.  The slot stays marked busy; the
+// ring's own synchronisation on reuse (jb_submit) then returns at once.
+void *jb_wait_begin_(jb_ctx *ctx, int ticket) {
+  for (int i = 0; i < ctx->n_slots; i++)
+    if (ctx->slots[i].ticket == ticket) return ctx->slots[i].busy ? (void *)ctx->slots[i].done : nullptr;
+  return nullptr;  // the slot has been reused: that submission completed long ago
+}
+int jb_wait_block_(jb_ctx *ctx, void *event) {
+  DeviceGuard guard(ctx->device);
+  hipError_t e = hipEventSynchronize((hipEvent_t)event);
+  if (e != hipSuccess) return fail(nullptr, JB_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+  return JB_OK;
+}
 
 // used by jb_frontend.cpp to report through the same channel
 int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%s", msg); }
