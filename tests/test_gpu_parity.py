@@ -106,8 +106,10 @@ def test_async_ring_many_images(jb, oracle):
             tickets.append(ctx.submit(desc, coef, q, out))
         # only the last n_slots tickets are still waitable; earlier ones completed when their
         # slot was recycled
+        assert isinstance(ctx.poll(tickets[-1]), bool)      # non-blocking: pending or done
         for t in tickets[-3:]:
             ctx.wait(t)
+            assert ctx.poll(t) is True
         with pytest.raises(jb.JbError) as e:
             ctx.wait(tickets[0])
         assert e.value.status == -7
