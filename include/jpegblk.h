@@ -61,7 +61,7 @@ typedef enum jb_status {
   JB_ERR_HIP = -6,         /* HIP runtime error; text via jb_last_error()                  */
   JB_ERR_STATE = -7,       /* bad ticket / nothing in flight / context busy                */
   JB_ERR_FORMAT = -8,      /* front end: not a JPEG / corrupt segment                      */
-  JB_ERR_UNSUPPORTED = -9  /* front end: progressive, !=3 components, ... (jpeg.cpp:69-87) */
+  JB_ERR_UNSUPPORTED = -9  /* front end: a frame type it does not decode (12-bit, arithmetic, 4 components ...) */
 } jb_status;
 
 /* What Image state the seam reads: image_width/height (jpeg.cpp:792-793), the luma sampling
@@ -159,11 +159,17 @@ const char *jb_kernel_name(const jb_image_desc *desc);
 
 /* ---- host front end ("next" rows of the scope table; reference jpeg.cpp:67-446, 826-907,
  *      include/file.hpp, include/huffman.hpp) --------------------------------------------- */
-/* Parse a baseline JFIF byte stream and Huffman-decode its scan into packed int16 blocks in
- * the order described above.  Two-call protocol: with coef == NULL only the headers are parsed
- * and *desc / qtabs are filled (size the buffer with jb_geometry_of); with coef != NULL
- * (capacity coef_cap_bytes) the scan is decoded too.  Rejects what the reference rejects
- * (progressive SOF2, != 3 components, chroma not 1x1, luma factors outside {1,2}). */
+/* Parse a JFIF byte stream and Huffman-decode it into packed int16 blocks in the order
+ * described above.  Two-call protocol: with coef == NULL only the headers are parsed and
+ * *desc / qtabs are filled (size the buffer with jb_geometry_of); with coef != NULL (capacity
+ * coef_cap_bytes) the entropy-coded data is decoded too.
+ * What the reference accepts -- baseline, three components, one interleaved scan -- takes the
+ * fast path and is integer-exact against the reference's decodeHuffman().  Beyond the reference
+ * (it rejects them, jpeg.cpp:69-87, 255-264): progressive frames (SOF2), frames coded in several
+ * scans, and grayscale frames, which are delivered as 4:4:4 with all-zero Cb/Cr blocks so that
+ * the pixel path yields R = G = B.  Still rejected: luma factors outside {1,2}, chroma not 1x1
+ * (JB_ERR_SAMPLING); 12-bit, lossless, hierarchical, arithmetic-coded, 2- or 4-component frames
+ * (JB_ERR_UNSUPPORTED). */
 int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                       uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes);
 /* The same with the restart intervals of ONE image (DRI; e.g. the reference's images/img4.jpg)

@@ -1,0 +1,234 @@
+// jb_entropy.h -- internal: the entropy-decoding primitives shared by the fast baseline front end
+// (jb_frontend.cpp) and the general multi-scan / progressive one (jb_frontend_ext.cpp): zig-zag
+// order, canonical Huffman tables with lookahead, the MSB-first bit reader, one sequential block.
+#ifndef JB_ENTROPY_H
+#define JB_ENTROPY_H
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "../../include/jpegblk.h"
+
+namespace jbe {
+
+// zig-zag position -> natural index (ITU-T T.81 Figure A.6; reference types.hpp:23-31)
+static const uint8_t kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                             12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                             58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffTable {
+  bool set = false;
+  uint8_t counts[17] = {0};
+  uint8_t symbols[256] = {0};
+  // canonical decode (reference huffman.hpp:17-29 generates the same codes)
+  int32_t maxcode[18];
+  int32_t valptr[17];
+  int32_t mincode[17];
+  // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
+  uint16_t fast[512];
+  // AC tables only: 9-bit lookahead that resolves code AND magnitude bits in one step when both
+  // fit in 9 bits: (value << 8) | (run << 4) | (code length + magnitude bits); 0 = take the
+  // general path
+  int16_t fast_ac[512];
+
+  bool build() {
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; len++) {
+      valptr[len] = k;
+      mincode[len] = code;
+      k += counts[len];
+      code += counts[len];
+      maxcode[len] = counts[len] ? code - 1 : -1;
+      if (code > (1 << len)) return false;  // over-subscribed
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+    memset(fast, 0, sizeof fast);
+    code = 0;
+    k = 0;
+    for (int len = 1; len <= 9; len++) {
+      for (int i = 0; i < counts[len]; i++, k++, code++) {
+        const int first = code << (9 - len);
+        for (int j = 0; j < (1 << (9 - len)); j++) fast[first + j] = (uint16_t)((len << 8) | symbols[k]);
+      }
+      code <<= 1;
+    }
+    // combined code + magnitude lookup (T.81 F.2.2.1 EXTEND folded in)
+    for (int i = 0; i < 512; i++) {
+      fast_ac[i] = 0;
+      const uint16_t f = fast[i];
+      if (!f) continue;
+      const int len = f >> 8, rs = f & 0xff, run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > 9) continue;
+      int k = ((i << len) & 511) >> (9 - mag);  // the magnitude bits that follow the code
+      if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;
+      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)((k * 256) + (run * 16) + (len + mag));
+    }
+    set = true;
+    return true;
+  }
+};
+
+struct Err {
+  int code = JB_OK;
+  std::string msg;
+};
+
+inline int set_err(Err &e, int code, const char *msg) {
+  e.code = code;
+  e.msg = msg;
+  return code;
+}
+
+// MSB-first bit reader over the stuffed scan bytes: FF00 -> FF, a marker stops the stream
+// (zero bits are supplied past it).  Reference equivalent: readImageData + BitStream
+// (file.hpp:59-104, 130-164).
+struct BitReader {
+  const uint8_t *p, *end;
+  uint64_t acc = 0;
+  int nbits = 0;
+  int marker = 0;  // pending marker byte (0 = none)
+  int pad = 0;     // zero bytes supplied past a marker / the end of the data
+
+  BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+
+  inline void refill() {
+    // fast path: 8 bytes at once when none of them is 0xFF (no stuffing, no marker)
+    if (!marker && p + 8 <= end) {
+      uint64_t w;
+      memcpy(&w, p, 8);
+      const uint64_t nw = ~w;  // a 0xFF byte in w is a zero byte in ~w
+      if ((((nw - 0x0101010101010101ull) & ~nw) & 0x8080808080808080ull) == 0) {
+        w = __builtin_bswap64(w);
+        const int take = (64 - nbits) >> 3;  // whole bytes that fit
+        if (take > 0) {
+          const uint64_t m = take == 8 ? ~0ull : ~(~0ull >> (8 * take));
+          acc |= (w & m) >> nbits;
+          p += take;
+          nbits += 8 * take;
+        }
+        return;
+      }
+    }
+    while (nbits <= 56) {
+      uint32_t byte = 0;
+      if (!marker && p < end) {
+        byte = *p++;
+        if (byte == 0xff) {
+          while (p < end && *p == 0xff) p++;  // fill bytes (reference file.hpp:88-91)
+          const uint8_t m = p < end ? *p++ : 0xd9;
+          if (m == 0) byte = 0xff;
+          else {
+            marker = m;
+            byte = 0;
+            pad++;
+          }
+        }
+      } else {
+        pad++;
+      }
+      acc |= (uint64_t)byte << (56 - nbits);
+      nbits += 8;
+    }
+  }
+  inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+  inline void drop(int n) {
+    acc <<= n;
+    nbits -= n;
+  }
+  inline uint32_t get(int n) {
+    if (n == 0) return 0;
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  // restart boundary: discard the partial byte, step over the RSTn marker
+  // (reference: BitStream::align, file.hpp:161-164, after readImageData dropped the marker)
+  // true when bits past the real data (padding zeros) have been consumed: truncated/corrupt
+  bool overran() const { return pad * 8 > nbits; }
+  bool restart() {
+    if (overran()) return false;
+    pad = 0;
+    if (!marker) {
+      // marker not reached by the lookahead yet: the remaining buffered bits are padding;
+      // scan forward to it
+      acc = 0;
+      nbits = 0;
+      while (p + 1 < end && !(p[0] == 0xff && p[1] >= 0xd0 && p[1] <= 0xd7)) p++;
+      if (p + 1 >= end) return false;
+      p += 2;
+      return true;
+    }
+    if (marker < 0xd0 || marker > 0xd7) return false;
+    marker = 0;
+    acc = 0;
+    nbits = 0;
+    return true;
+  }
+};
+
+inline int decode_symbol(BitReader &br, const HuffTable &t) {
+  if (br.nbits < 32) br.refill();
+  const uint32_t look = br.peek(9);
+  const uint16_t f = t.fast[look];
+  if (f) {
+    br.drop(f >> 8);
+    return f & 0xff;
+  }
+  int32_t code = (int32_t)br.peek(10);
+  int len = 10;
+  while (len <= 16 && code > t.maxcode[len]) {
+    len++;
+    code = (int32_t)br.peek(len);
+  }
+  if (len > 16) return -1;
+  br.drop(len);
+  return t.symbols[t.valptr[len] + code - t.mincode[len]];
+}
+
+inline int extend(uint32_t v, int n) {
+  // T.81 F.2.2.1 EXTEND; reference jpeg.cpp:340-343, 394-397
+  return (int)v < (1 << (n - 1)) ? (int)v - (1 << n) + 1 : (int)v;
+}
+
+// one block, reference decodeMCUComponent (jpeg.cpp:322-403)
+inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac, int &pred, int16_t *out) {
+  memset(out, 0, 128);
+  const int s = decode_symbol(br, dc);
+  if (s < 0 || s > 11) return false;
+  const int diff = s ? extend(br.get(s), s) : 0;  // decode_symbol left >= 16 bits buffered
+  pred += diff;
+  if (pred < -32768 || pred > 32767) return false;
+  out[0] = (int16_t)pred;
+  int k = 1;
+  while (k < 64) {
+    if (br.nbits < 32) br.refill();
+    const int fa = ac.fast_ac[br.peek(9)];
+    if (fa) {  // code and magnitude resolved by one lookup
+      k += (fa >> 4) & 15;
+      if (k > 63) return false;  // reference jpeg.cpp:372-376
+      br.drop(fa & 15);
+      out[kZigZag[k++]] = (int16_t)(fa >> 8);
+      continue;
+    }
+    const int rs = decode_symbol(br, ac);
+    if (rs < 0) return false;
+    if (rs == 0) break;  // EOB
+    int r = rs >> 4;
+    const int n = rs & 15;
+    if (rs == 0xf0) r = 16;
+    if (k + r >= 64 || n > 10) return false;  // reference jpeg.cpp:372-385
+    k += r;
+    if (n) {
+      out[kZigZag[k]] = (int16_t)extend(br.get(n), n);  // <= 16 + 10 bits since the last refill
+      k++;
+    }
+  }
+  return true;
+}
+
+}  // namespace jbe
+
+#endif  // JB_ENTROPY_H

@@ -1,0 +1,440 @@
+// jb_frontend_ext.cpp -- the general host front end: what the fast baseline path
+// (jb_frontend.cpp) turns away but ITU-T T.81 allows and real files contain:
+//   * progressive DCT frames (SOF2): spectral selection + successive approximation, Annex G;
+//   * grayscale frames (one component);
+//   * sequential frames coded in several scans (non-interleaved components).
+// All of this is BEYOND the reference, which rejects such files (jpeg.cpp:69-73, 83-87,
+// 255-264) -- SURVEY.md section 8f rank 4.  There is no reference oracle for it; it is pinned by
+// (a) libjpeg's encoder being deterministic: the baseline and the progressive encoding of the
+// same pixels hold the same quantised coefficients, and the baseline file goes through the front
+// end that is integer-exact against the reference; (b) closeness to libjpeg's own decode of the
+// same file (tests/test_abi.py, tests/test_gpu_parity.py).
+//
+// Output is what the device seam consumes, exactly as for baseline files: int16 coefficient
+// blocks in MCU-interleaved order.  A grayscale frame is delivered as a 4:4:4 frame whose Cb and
+// Cr blocks are all zero: the reference's colour formulas (jpeg.cpp:521-523) then give
+// R = G = B = Y + 128, so the fused kernel needs no second code path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/jpegblk.h"
+#include "jb_entropy.h"
+
+namespace {
+
+using namespace jbe;
+
+struct Comp {
+  int id = 0, h = 1, v = 1, tq = 0;
+  int bw = 0, bh = 0;  // the component's own block grid (non-interleaved scans)
+};
+
+struct Scan {
+  int ns = 0;
+  int ci[3] = {0, 0, 0};          // frame component index of each scan component
+  int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+  int ss = 0, se = 63, ah = 0, al = 0;
+};
+
+struct Ext {
+  jb_image_desc desc;
+  jb_geometry g;
+  int ncomp = 0;
+  bool have_sof = false, progressive = false;
+  Comp comp[3];
+  uint16_t qtabs[4][64];
+  bool qset[4] = {false, false, false, false};
+  HuffTable dc[4], ac[4];
+  int restart_interval = 0;
+  int16_t *coef = nullptr;
+  int ny = 1, bpm = 3;
+
+  // block (by, bx) of frame component c -> its place in the MCU-interleaved array
+  inline int16_t *block(int c, int by, int bx) const {
+    int64_t idx;
+    if (c == 0) {
+      const int hs = desc.hs, vs = desc.vs;
+      idx = ((int64_t)(by / vs) * g.mcus_x + bx / hs) * bpm + (by % vs) * hs + bx % hs;
+    } else {
+      idx = ((int64_t)by * g.mcus_x + bx) * bpm + ny + c - 1;
+    }
+    return coef + idx * 64;
+  }
+};
+
+inline bool fits16(int v) { return v >= -32768 && v <= 32767; }
+
+// ---- one block of each scan type (T.81 F.2.2 sequential, G.2 progressive) ----
+
+inline bool dc_first(BitReader &br, const HuffTable &t, int &pred, int al, int16_t *blk) {
+  const int s = decode_symbol(br, t);
+  if (s < 0 || s > 15) return false;
+  const int diff = s ? extend(br.get(s), s) : 0;
+  pred += diff;
+  const int v = pred * (1 << al);
+  if (!fits16(pred) || !fits16(v)) return false;
+  blk[0] = (int16_t)v;
+  return true;
+}
+
+inline void dc_refine(BitReader &br, int al, int16_t *blk) {
+  if (br.nbits < 32) br.refill();
+  if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << al));
+}
+
+inline bool ac_first(BitReader &br, const HuffTable &t, int ss, int se, int al, int &eobrun, int16_t *blk) {
+  if (eobrun > 0) {
+    eobrun--;
+    return true;
+  }
+  for (int k = ss; k <= se;) {
+    const int rs = decode_symbol(br, t);
+    if (rs < 0) return false;
+    const int r = rs >> 4, s = rs & 15;
+    if (s) {
+      k += r;
+      if (k > se) return false;
+      const int v = extend(br.get(s), s) * (1 << al);
+      if (!fits16(v)) return false;
+      blk[kZigZag[k++]] = (int16_t)v;
+    } else if (r == 15) {
+      k += 16;  // ZRL
+    } else {    // EOBn: this block and the next 2^r - 1 + extra are finished in this band
+      eobrun = (1 << r) - 1;
+      if (r) {
+        if (br.nbits < 32) br.refill();
+        eobrun += (int)br.get(r);
+      }
+      break;
+    }
+  }
+  return true;
+}
+
+// successive-approximation refinement of an AC band (T.81 G.1.2.3, Figure G.7): coefficients that
+// are already non-zero receive one correction bit each; newly non-zero ones arrive as +-1 << Al
+// after a run that counts only still-zero coefficients
+inline bool ac_refine(BitReader &br, const HuffTable &t, int ss, int se, int al, int &eobrun, int16_t *blk) {
+  const int p1 = 1 << al, m1 = -(1 << al);
+  auto correct = [&](int16_t *c) {
+    if (br.nbits < 32) br.refill();
+    if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+  };
+  int k = ss;
+  if (eobrun == 0) {
+    while (k <= se) {
+      const int rs = decode_symbol(br, t);
+      if (rs < 0) return false;
+      int r = rs >> 4;
+      const int s = rs & 15;
+      int value = 0;
+      if (s) {
+        if (s != 1) return false;
+        if (br.nbits < 32) br.refill();
+        value = br.get(1) ? p1 : m1;
+      } else if (r != 15) {
+        eobrun = 1 << r;  // counts this block as well
+        if (r) {
+          if (br.nbits < 32) br.refill();
+          eobrun += (int)br.get(r);
+        }
+        break;
+      }
+      // skip r still-zero coefficients, correcting the non-zero ones passed on the way
+      while (k <= se) {
+        int16_t *c = &blk[kZigZag[k]];
+        if (*c != 0) correct(c);
+        else if (--r < 0) break;
+        k++;
+      }
+      if (s) {
+        if (k > se) return false;
+        blk[kZigZag[k]] = (int16_t)value;
+      }
+      k++;
+    }
+  }
+  if (eobrun > 0) {  // the rest of the band: correction bits only
+    for (; k <= se; k++) {
+      int16_t *c = &blk[kZigZag[k]];
+      if (*c != 0) correct(c);
+    }
+    eobrun--;
+  }
+  return true;
+}
+
+// One scan over its entropy-coded segment [b, e).
+int decode_one_scan(Ext &x, const Scan &sc, const uint8_t *b, const uint8_t *e, Err &err) {
+  BitReader br(b, e);
+  int pred[3] = {0, 0, 0};
+  int eobrun = 0;
+  const bool sequential = !x.progressive;
+  auto one_block = [&](int k, int16_t *blk) -> bool {  // k = index within the scan
+    const int c = sc.ci[k];
+    if (sequential) return decode_block(br, x.dc[sc.td[k]], x.ac[sc.ta[k]], pred[c], blk);
+    if (sc.ss == 0) {
+      if (sc.ah == 0) return dc_first(br, x.dc[sc.td[k]], pred[c], sc.al, blk);
+      dc_refine(br, sc.al, blk);
+      return true;
+    }
+    if (sc.ah == 0) return ac_first(br, x.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+    return ac_refine(br, x.ac[sc.ta[k]], sc.ss, sc.se, sc.al, eobrun, blk);
+  };
+  auto at_restart = [&]() -> bool {
+    if (!br.restart()) return false;
+    pred[0] = pred[1] = pred[2] = 0;
+    eobrun = 0;
+    return true;
+  };
+  int until_restart = x.restart_interval;
+  if (sc.ns == 1) {  // non-interleaved: the component's own block raster, one block per MCU
+    const int c = sc.ci[0];
+    const Comp &cp = x.comp[c];
+    for (int by = 0; by < cp.bh; by++) {
+      // out of data: stop now rather than run the rest of a huge frame on padding zeros
+      if (br.overran()) return set_err(err, JB_ERR_FORMAT, "entropy-coded data ends early");
+      for (int bx = 0; bx < cp.bw; bx++) {
+        if (x.restart_interval && until_restart == 0) {
+          if (!at_restart()) return set_err(err, JB_ERR_FORMAT, "restart marker missing");
+          until_restart = x.restart_interval;
+        }
+        if (!one_block(0, x.block(c, by, bx))) return set_err(err, JB_ERR_FORMAT, "corrupt entropy-coded data");
+        until_restart--;
+      }
+    }
+  } else {  // interleaved: MCUs in raster order, per MCU the blocks of each scan component
+    for (int my = 0; my < x.g.mcus_y; my++) {
+      if (br.overran()) return set_err(err, JB_ERR_FORMAT, "entropy-coded data ends early");
+      for (int mx = 0; mx < x.g.mcus_x; mx++) {
+        if (x.restart_interval && until_restart == 0) {
+          if (!at_restart()) return set_err(err, JB_ERR_FORMAT, "restart marker missing");
+          until_restart = x.restart_interval;
+        }
+        for (int k = 0; k < sc.ns; k++) {
+          const int c = sc.ci[k];
+          const int h = c == 0 ? x.desc.hs : 1, v = c == 0 ? x.desc.vs : 1;
+          for (int bv = 0; bv < v; bv++)
+            for (int bh = 0; bh < h; bh++)
+              if (!one_block(k, x.block(c, my * v + bv, mx * h + bh)))
+                return set_err(err, JB_ERR_FORMAT, "corrupt entropy-coded data");
+        }
+        until_restart--;
+      }
+    }
+  }
+  if (br.overran()) return set_err(err, JB_ERR_FORMAT, "entropy-coded data ends early");
+  return JB_OK;
+}
+
+// end of an entropy-coded segment: the next marker that is not RSTn (FF00 is a stuffed byte)
+size_t segment_end(const uint8_t *d, size_t pos, size_t n) {
+  while (pos + 1 < n) {
+    if (d[pos] != 0xff) {
+      pos++;
+      continue;
+    }
+    const uint8_t m = d[pos + 1];
+    if (m == 0x00 || (m >= 0xd0 && m <= 0xd7)) pos += 2;
+    else if (m == 0xff) pos++;
+    else return pos;
+  }
+  return n;
+}
+
+int parse_sof(Ext &x, const uint8_t *s, size_t sl, Err &e) {
+  if (x.have_sof) return set_err(e, JB_ERR_FORMAT, "more than one frame header");
+  if (sl < 6) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
+  if (s[0] != 8) return set_err(e, JB_ERR_UNSUPPORTED, "only 8-bit precision is supported");
+  x.desc.height = (s[1] << 8) | s[2];
+  x.desc.width = (s[3] << 8) | s[4];
+  x.ncomp = s[5];
+  if (x.ncomp != 1 && x.ncomp != 3) return set_err(e, JB_ERR_UNSUPPORTED, "only 1 or 3 components are supported");
+  if (sl < 6 + 3u * (unsigned)x.ncomp) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
+  if (x.desc.width < 1 || x.desc.height < 1) return set_err(e, JB_ERR_GEOMETRY, "empty image");
+  for (int c = 0; c < x.ncomp; c++) {
+    Comp &cp = x.comp[c];
+    cp.id = s[6 + 3 * c];
+    cp.h = s[7 + 3 * c] >> 4;
+    cp.v = s[7 + 3 * c] & 15;
+    cp.tq = s[8 + 3 * c];
+    if (cp.tq > 3) return set_err(e, JB_ERR_QTAB, "quantisation table id > 3");
+    if (cp.h < 1 || cp.h > 4 || cp.v < 1 || cp.v > 4) return set_err(e, JB_ERR_SAMPLING, "bad sampling factor");
+  }
+  if (x.ncomp == 3) {
+    if (x.comp[0].h > 2 || x.comp[0].v > 2) return set_err(e, JB_ERR_SAMPLING, "luma sampling factors must be 1 or 2");
+    if (x.comp[1].h != 1 || x.comp[1].v != 1 || x.comp[2].h != 1 || x.comp[2].v != 1)
+      return set_err(e, JB_ERR_SAMPLING, "chroma sampling factors must be 1x1");
+    x.desc.hs = x.comp[0].h;
+    x.desc.vs = x.comp[0].v;
+    for (int c = 0; c < 3; c++) x.desc.qtab_id[c] = x.comp[c].tq;
+  } else {  // one component: its sampling factors are irrelevant (always non-interleaved)
+    x.desc.hs = x.desc.vs = 1;
+    x.comp[0].h = x.comp[0].v = 1;
+    for (int c = 0; c < 3; c++) x.desc.qtab_id[c] = x.comp[0].tq;  // Cb = Cr = 0: any table does
+  }
+  x.desc.reserved = 0;
+  int rc = jb_geometry_of(&x.desc, &x.g);
+  if (rc) return set_err(e, rc, "bad frame geometry");
+  x.ny = x.desc.hs * x.desc.vs;
+  x.bpm = x.g.blocks_per_mcu;
+  const int W = x.desc.width, H = x.desc.height;
+  for (int c = 0; c < x.ncomp; c++) {  // component size = ceil(size * h / hmax), in blocks
+    const int cw = c == 0 ? W : (W + x.desc.hs - 1) / x.desc.hs;
+    const int ch = c == 0 ? H : (H + x.desc.vs - 1) / x.desc.vs;
+    x.comp[c].bw = (cw + 7) / 8;
+    x.comp[c].bh = (ch + 7) / 8;
+  }
+  x.have_sof = true;
+  return JB_OK;
+}
+
+int parse_sos(Ext &x, const uint8_t *s, size_t sl, Scan &sc, Err &e) {
+  if (!x.have_sof) return set_err(e, JB_ERR_FORMAT, "SOS before SOF");
+  if (sl < 1) return set_err(e, JB_ERR_FORMAT, "bad SOS segment");
+  sc.ns = s[0];
+  if (sc.ns < 1 || sc.ns > x.ncomp) return set_err(e, JB_ERR_FORMAT, "bad number of scan components");
+  if (sl != 1 + 2u * (unsigned)sc.ns + 3) return set_err(e, JB_ERR_FORMAT, "bad SOS length");
+  int last = -1;
+  for (int k = 0; k < sc.ns; k++) {
+    int c = -1;
+    for (int j = 0; j < x.ncomp; j++)
+      if (x.comp[j].id == s[1 + 2 * k]) c = j;
+    if (c < 0 || c <= last) return set_err(e, JB_ERR_FORMAT, "scan component not in frame order");
+    last = c;
+    sc.ci[k] = c;
+    sc.td[k] = s[2 + 2 * k] >> 4;
+    sc.ta[k] = s[2 + 2 * k] & 15;
+    if (sc.td[k] > 3 || sc.ta[k] > 3) return set_err(e, JB_ERR_FORMAT, "bad Huffman table id in SOS");
+  }
+  const uint8_t *t = s + 1 + 2 * sc.ns;
+  sc.ss = t[0];
+  sc.se = t[1];
+  sc.ah = t[2] >> 4;
+  sc.al = t[2] & 15;
+  if (x.progressive) {
+    if (sc.ss > 63 || sc.se > 63 || sc.se < sc.ss || sc.al > 13 || sc.ah > 13)
+      return set_err(e, JB_ERR_FORMAT, "bad progressive scan parameters");
+    if (sc.ss == 0 && sc.se != 0) return set_err(e, JB_ERR_FORMAT, "a DC scan must not carry AC coefficients");
+    if (sc.ss > 0 && sc.ns != 1) return set_err(e, JB_ERR_FORMAT, "an AC scan holds one component");
+    if (sc.ah != 0 && sc.ah != sc.al + 1) return set_err(e, JB_ERR_FORMAT, "bad successive approximation");
+  } else if (sc.ss != 0 || sc.se != 63 || sc.ah != 0 || sc.al != 0) {
+    return set_err(e, JB_ERR_UNSUPPORTED, "sequential scans must cover coefficients 0..63");
+  }
+  for (int k = 0; k < sc.ns; k++) {
+    const bool need_dc = !x.progressive || (sc.ss == 0 && sc.ah == 0);
+    const bool need_ac = !x.progressive || sc.ss > 0;
+    if (need_dc && !x.dc[sc.td[k]].set) return set_err(e, JB_ERR_FORMAT, "Huffman DC table not found");
+    if (need_ac && !x.ac[sc.ta[k]].set) return set_err(e, JB_ERR_FORMAT, "Huffman AC table not found");
+  }
+  return JB_OK;
+}
+
+int run(const uint8_t *d, size_t n, Ext &x, size_t coef_cap_bytes, bool headers_only, Err &e) {
+  if (!d || n < 4 || d[0] != 0xff || d[1] != 0xd8) return set_err(e, JB_ERR_FORMAT, "not a JPEG file (no SOI)");
+  memset(x.qtabs, 0, sizeof x.qtabs);
+  size_t pos = 2;
+  int scans = 0;
+  while (true) {
+    if (pos + 1 >= n) {
+      if (scans > 0) return JB_OK;  // no EOI: everything that was coded has been decoded
+      return set_err(e, JB_ERR_FORMAT, "truncated file (no SOS)");
+    }
+    if (d[pos] != 0xff) return set_err(e, JB_ERR_FORMAT, "marker expected");
+    while (pos < n && d[pos] == 0xff) pos++;
+    if (pos >= n) return scans > 0 ? JB_OK : set_err(e, JB_ERR_FORMAT, "truncated file");
+    const uint8_t m = d[pos++];
+    if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;  // no payload
+    if (m == 0xd9) {
+      if (scans == 0) return set_err(e, JB_ERR_FORMAT, "EOI before SOS");
+      return JB_OK;
+    }
+    if (pos + 2 > n) return set_err(e, JB_ERR_FORMAT, "truncated segment");
+    const size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+    if (len < 2 || pos + len > n) return set_err(e, JB_ERR_FORMAT, "bad segment length");
+    const uint8_t *s = d + pos + 2;
+    const size_t sl = len - 2;
+    pos += len;
+    if (m == 0xdb) {  // DQT
+      size_t i = 0;
+      while (i < sl) {
+        const int pq = s[i] >> 4, tq = s[i] & 15;
+        i++;
+        if (tq > 3) return set_err(e, JB_ERR_QTAB, "quantisation table id > 3");
+        const size_t need = pq ? 128 : 64;
+        if (pq > 1 || i + need > sl) return set_err(e, JB_ERR_FORMAT, "bad DQT segment");
+        for (int k = 0; k < 64; k++)
+          x.qtabs[tq][kZigZag[k]] = pq ? (uint16_t)((s[i + 2 * k] << 8) | s[i + 2 * k + 1]) : s[i + k];
+        x.qset[tq] = true;
+        i += need;
+      }
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // baseline / extended sequential / progressive, Huffman
+      x.progressive = (m == 0xc2);
+      int rc = parse_sof(x, s, sl, e);
+      if (rc) return rc;
+      if (!headers_only) {
+        if ((size_t)x.g.coef_bytes > coef_cap_bytes) return set_err(e, JB_ERR_CAPACITY, "coefficient buffer too small");
+        memset(x.coef, 0, (size_t)x.g.coef_bytes);  // scans add to it; grayscale leaves Cb, Cr at zero
+      }
+    } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+      return set_err(e, JB_ERR_UNSUPPORTED, "lossless, hierarchical and arithmetic-coded frames are not supported");
+    } else if (m == 0xc4) {  // DHT
+      size_t i = 0;
+      while (i < sl) {
+        if (i + 17 > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        if (th > 3 || tc > 1) return set_err(e, JB_ERR_FORMAT, "bad Huffman table id");
+        HuffTable &t = tc ? x.ac[th] : x.dc[th];
+        int total = 0;
+        t.counts[0] = 0;
+        for (int l = 1; l <= 16; l++) {
+          t.counts[l] = s[i + l];
+          total += s[i + l];
+        }
+        i += 17;
+        if (total > 256 || i + total > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
+        memcpy(t.symbols, s + i, (size_t)total);
+        i += (size_t)total;
+        if (!t.build()) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
+      }
+    } else if (m == 0xdd) {  // DRI
+      if (sl != 2) return set_err(e, JB_ERR_FORMAT, "bad DRI segment");
+      x.restart_interval = (s[0] << 8) | s[1];
+    } else if (m == 0xda) {  // SOS + its entropy-coded segment
+      Scan sc;
+      int rc = parse_sos(x, s, sl, sc, e);
+      if (rc) return rc;
+      for (int c = 0; c < x.ncomp; c++)
+        if (!x.qset[x.comp[c].tq]) return set_err(e, JB_ERR_QTAB, "quantisation table not found");
+      if (headers_only) return JB_OK;
+      const size_t end = segment_end(d, pos, n);
+      rc = decode_one_scan(x, sc, d + pos, d + end, e);
+      if (rc) return rc;
+      scans++;
+      pos = end;
+    }
+    // APPn, COM, anything else with a length: ignored
+  }
+}
+
+}  // namespace
+
+// Entry point for jb_frontend.cpp.  coef == nullptr: headers only (desc and the tables seen before
+// the first scan).  Returns a jb_status; *err receives the message.
+int jb_ext_decode_(const uint8_t *jpeg, size_t n, jb_image_desc *desc, uint16_t *qtabs, int16_t *coef,
+                   size_t coef_cap_bytes, std::string *err) {
+  Ext *x = new Ext();
+  x->coef = coef;
+  Err e;
+  int rc = run(jpeg, n, *x, coef_cap_bytes, coef == nullptr, e);
+  if (rc == JB_OK) {
+    *desc = x->desc;
+    if (qtabs) memcpy(qtabs, x->qtabs, sizeof x->qtabs);
+  } else if (err) {
+    *err = e.msg;
+  }
+  delete x;
+  return rc;
+}

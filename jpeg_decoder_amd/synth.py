@@ -146,18 +146,20 @@ def _writer_lib():
             subprocess.run(["make", "-C", d], check=True, capture_output=True)
         L = ctypes.CDLL(so)
         vp = ctypes.c_void_p
-        L.jw_encode.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
-                                ctypes.c_int, ctypes.c_int, vp, ctypes.c_long]
-        L.jw_encode.restype = ctypes.c_long
+        L.jw_encode_ex.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_long]
+        L.jw_encode_ex.restype = ctypes.c_long
         _writer = L
     return _writer
 
 
 def encode_jpeg(coef, width, height, hs, vs, qtabs, qtab_id=(0, 1, 1), restart_interval=0, dqt16=False,
-                huffman=ANNEX_K_HUFFMAN):
+                huffman=ANNEX_K_HUFFMAN, per_component_scans=False):
     """Coefficient blocks (int16 [n, 64], natural order, decode order -- the device seam's input)
     -> a baseline JFIF byte stream that entropy-decodes to exactly those blocks.  restart_interval
-    in MCUs.  Requires |DC difference| <= 2047 and |AC| <= 1023 (the baseline symbol alphabet)."""
+    in MCUs.  Requires |DC difference| <= 2047 and |AC| <= 1023 (the baseline symbol alphabet).
+    per_component_scans: three non-interleaved scans instead of one interleaved scan (the
+    reference cannot read those; blocks that only pad the frame to whole MCUs are then not coded)."""
     import ctypes
     coef = np.ascontiguousarray(coef, np.int16)
     n = geometry(width, height, hs, vs)[3]
@@ -173,8 +175,9 @@ def encode_jpeg(coef, width, height, hs, vs, qtabs, qtab_id=(0, 1, 1), restart_i
         dht[t, 16:16 + len(vals)] = vals
     cap = 1024 + coef.size * 4  # worst case: 16-bit code + 10/11 value bits per coefficient, stuffed
     out = np.empty(cap, np.uint8)
-    r = _writer_lib().jw_encode(coef.ctypes.data, width, height, hs, vs, q.ctypes.data, ids.ctypes.data,
-                                dht.ctypes.data, restart_interval, int(bool(dqt16)), out.ctypes.data, cap)
+    r = _writer_lib().jw_encode_ex(coef.ctypes.data, width, height, hs, vs, q.ctypes.data, ids.ctypes.data,
+                                   dht.ctypes.data, restart_interval, int(bool(dqt16)), int(bool(per_component_scans)),
+                                   out.ctypes.data, cap)
     if r < 0:
         raise ValueError({-1: "bad argument", -2: "output buffer too small", -3: "value not encodable in baseline"}.get(r, str(r)))
     return out[:r].tobytes()

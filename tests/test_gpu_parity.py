@@ -54,10 +54,35 @@ def test_decode_file_matches_reference(jb, big_ctx, name):
     assert np.array_equal(got, rgb)
 
 
-def test_decode_file_rejects_progressive(jb, big_ctx):
-    with pytest.raises(jb.JbError) as e:
-        big_ctx.decode_file(os.path.join(GOLD, "images", "prograssive-sample-2.jpg"))
-    assert e.value.status == -9
+def test_decode_file_progressive_and_grayscale(jb, big_ctx, oracle, tmp_path):
+    """Beyond the reference (it rejects both, jpeg.cpp:69-87): decode(path) of progressive and of
+    grayscale files equals the oracle's pixel path on the decoded blocks; a progressive file gives
+    exactly the pixels of the baseline file of the same image; the reference's own bundled
+    progressive sample decodes and stays close to libjpeg's decode."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from oracle.pyoracle import make_desc as odesc
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:301, 0:457]
+    img = np.clip(np.stack([xx * 0.4 + yy * 0.3, 220 - yy * 0.5, (xx + yy) * 0.3 + 20], -1)
+                  + rng.normal(0, 5, (301, 457, 3)), 0, 255).astype(np.uint8)
+    for sub in (0, 2):
+        pb, pp = tmp_path / f"b{sub}.jpg", tmp_path / f"p{sub}.jpg"
+        Image.fromarray(img).save(pb, "JPEG", quality=90, subsampling=sub)
+        Image.fromarray(img).save(pp, "JPEG", quality=90, subsampling=sub, progressive=True)
+        base, prog = big_ctx.decode_file(str(pb)), big_ctx.decode_file(str(pp))
+        assert np.array_equal(base, prog)
+        desc, q, coef = jb.entropy_decode(pp.read_bytes())
+        assert np.array_equal(prog, oracle.blocks_to_rgb(odesc(457, 301, desc.hs, desc.vs, list(desc.qtab_id)), coef, q))
+    pg = tmp_path / "g.jpg"
+    Image.fromarray(img).convert("L").save(pg, "JPEG", quality=90)
+    gray = big_ctx.decode_file(str(pg))
+    assert np.array_equal(gray[..., 0], gray[..., 1]) and np.array_equal(gray[..., 0], gray[..., 2])
+    assert np.abs(gray[..., 0].astype(int) - np.asarray(Image.open(pg)).astype(int)).max() <= 3
+    path = os.path.join(GOLD, "images", "prograssive-sample-2.jpg")
+    got = big_ctx.decode_file(path)
+    ref = np.asarray(Image.open(path).convert("RGB")).astype(int)
+    assert got.shape == ref.shape and np.abs(got.astype(int) - ref).mean() < 2.5
 
 
 @pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
@@ -251,7 +276,11 @@ def test_decode_batch_threads_and_failures(jb, tmp_path):
     the device stage; a rejected file in the middle is reported per file, the rest decode."""
     names = BASELINE_IMAGES * 3
     paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
-    paths.insert(4, os.path.join(GOLD, "images", "prograssive-sample-2.jpg"))
+    # an unsupported frame in the middle: four components (patched Nf of a good file)
+    good = bytearray(open(paths[0], "rb").read())
+    good[good.index(b"\xff\xc0") + 9] = 4
+    (tmp_path / "four.jpg").write_bytes(bytes(good))
+    paths.insert(4, str(tmp_path / "four.jpg"))
     paths.insert(9, str(tmp_path / "missing.jpg"))
     imgs, statuses, times = jb.decode_batch(paths, n_threads=4)
     assert times["rc"] == -9 or times["rc"] == -8
