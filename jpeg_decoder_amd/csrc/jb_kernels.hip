@@ -201,7 +201,7 @@ __device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-struct __attribute__((packed, aligned(4))) dw3_t {
+struct __attribute__((packed, aligned(1))) dw3_t {  // 12-byte store at any byte address
   uint32_t x, y, z;
 };
 
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
               __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, LINEAR ? rel * 3 : lane_late * 12, 0, JB_STORE_AUX);
             }
             if (!p.fast_store || (npx & 3)) {
-              // unaligned output, or the one group that straddles the right edge: byte stores
+              // the byte-store knob, or the one group that straddles the right edge: byte stores
               const int first = p.fast_store ? (npx & ~3) : 0;
               // opaque copy of a value that is live anyway: keeps this rare path's address
               // arithmetic from being hoisted out of the loop into registers
