@@ -102,7 +102,7 @@ def main():
     backend = os.environ.get("JB_BENCH_BACKEND", "nccl")  # "nccl" = RCCL on ROCm
     if os.environ.get("JB_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    if world > 1 or os.environ.get("JB_BENCH_FORCE_DIST") == "1":  # the latter: rehearse the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
