@@ -63,6 +63,12 @@ def cpu_baseline(coef, qtabs, budget_s=12.0):
     if not out:
         out = {"value": round(port1, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                "sample": f"{reps} x one {WIDTH}x{HEIGHT} 4:4:4 image through oracle/jpegblk_oracle.c (gcc -O2), {s1:.1f} s"}
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        model = "unknown"
+    out["cpu_model"] = model
+    out["flags"] = "reference harness: g++ -O2 -fno-access-control -U_FORTIFY_SOURCE (oracle/Makefile); port: gcc -O2 -ffp-contract=off; no -march=native, no -ffast-math"
     out["port_1core_mpix_s"] = round(port1, 2)
     out["port_allcores_mpix_s"] = round(mpix * reps_mt / smt, 2)
     out["port_allcores_threads"] = nthr
