@@ -399,3 +399,32 @@ def test_randomised_soak_short():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLD), "..", "tools", "stress.py"), "--seconds", "8", "--seed", "3"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_cpp_image_mirror_cli(tmp_path):
+    """include/jpegblk.hpp mirrors the reference's `Image` class (Image(path); readJPEG();
+    saveToBMP()): tools/decode_cli.cpp is the reference's main() (jpeg.cpp:916-929) written against
+    it.  Its PPM and BMP outputs must hold exactly the golden pixels; a rejected file exits 1
+    with the reference's "-> ERROR" style message."""
+    import subprocess
+    pytest.importorskip("PIL")
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(GOLD))
+    cli = os.path.join(root, "tools", "decode_cli")
+    if not os.path.exists(cli):
+        b = subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "decode_cli.cpp"),
+                            "-L" + os.path.join(root, "jpeg_decoder_amd"), "-ljpegblk",
+                            "-Wl,-rpath," + os.path.join(root, "jpeg_decoder_amd"), "-o", cli], capture_output=True, text=True)
+        assert b.returncode == 0, b.stderr[-2000:]
+    src = os.path.join(GOLD, "images", "img.jpg")
+    _, _, _, want = load_golden("img")
+    for ext in ("ppm", "bmp"):
+        out = tmp_path / f"o.{ext}"
+        r = subprocess.run([cli, src, str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{want.shape[1]}x{want.shape[0]}" in r.stdout
+        assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), want)
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"not a jpeg")
+    r = subprocess.run([cli, str(bad)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "ERROR" in r.stderr
