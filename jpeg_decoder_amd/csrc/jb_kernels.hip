@@ -266,6 +266,14 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
   constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
   constexpr bool kPermChroma = (VS == 2) && (NYT % 64 == 0);  // 4:2:0: chroma blocks fill a whole wave
+  // JB_SPLIT_ROWPASS (experiment): the row passes of register rows 4-7 -- what the second colour
+  // phase consumes -- run after the first phase's colour loop instead of before it, so that the
+  // first stores of a workgroup leave earlier and that quarter of the IDCT overlaps them
+#ifdef JB_SPLIT_ROWPASS
+  constexpr bool kSplitRows = (VS == 1) || kPermChroma;
+#else
+  constexpr bool kSplitRows = false;
+#endif
   constexpr bool kDirectLoad = !((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192));  // all but 4:4:4
   __shared__ __attribute__((aligned(1024))) char lds[kStripBytes];
   const int tid = threadIdx.x;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
              v[6 * 8 + i], v[7 * 8 + i]), JB_SCHED_FENCE();
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
+  for (int k = 0; k < (kSplitRows ? 4 : 8); k++)  // row pass, jpeg.cpp:664-731
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
            v[k * 8 + 6], v[k * 8 + 7]), JB_SCHED_FENCE();
   }
@@ -461,6 +469,14 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
 
 #pragma unroll
   for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1 && kSplitRows && JB_DO_IDCT(p)) {
+#pragma unroll
+      for (int i = 32; i < 64; i++) asm volatile("" : "+v"(v[i]));  // pins these row passes here
+#pragma unroll
+      for (int k = 4; k < 8; k++)
+        aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
+               v[k * 8 + 6], v[k * 8 + 7]);
+    }
     if (phase == 1) lds_barrier();  // phase-0 colour reads are done: the strips may be rewritten
     // Every lane contributes rows 4*phase..4*phase+3 of its block (so half of every block is
     // consumed per phase and only 32 values wait in registers).  Luma block-row bv lands in
