@@ -4,7 +4,8 @@
 //   * grayscale frames (one component);
 //   * sequential frames coded in several scans (non-interleaved components).
 // All of this is BEYOND the reference, which rejects such files (jpeg.cpp:69-73, 83-87,
-// 255-264) -- SURVEY.md section 8f rank 4.  There is no reference oracle for it; it is pinned by
+// 255-264) -- SURVEY.md section 8f rank 4.  Against the reference its parity is UNPINNED by
+// construction (the reference has no behaviour here to compare with); it is pinned externally by
 // (a) libjpeg's encoder being deterministic: the baseline and the progressive encoding of the
 // same pixels hold the same quantised coefficients, and the baseline file goes through the front
 // end that is integer-exact against the reference; (b) closeness to libjpeg's own decode of the
