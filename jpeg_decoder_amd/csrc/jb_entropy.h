@@ -10,6 +10,10 @@
 
 #include "../../include/jpegblk.h"
 
+#ifndef JB_WIDE_BITS
+#define JB_WIDE_BITS 11
+#endif
+
 namespace jbe {
 
 // zig-zag position -> natural index (ITU-T T.81 Figure A.6; reference types.hpp:23-31)
@@ -28,12 +32,13 @@ struct HuffTable {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
   uint16_t fast[512];
-  // AC tables only: 9-bit lookahead that resolves code AND magnitude bits in one step when both
-  // fit in 9 bits: (value << 8) | (run << 4) | (code length + magnitude bits); 0 = take the
-  // general path
-  int16_t fast_ac[512];
+  // AC tables only: kWideBits-bit lookahead that resolves the run/size code AND its magnitude bits
+  // in one step when both fit: (value << 16) | (control << 8) | bits consumed; control = run
+  // (0..16) | 0x40 for EOB | 0x80 for "no value" (ZRL); 0 = take the general path
+  static constexpr int kWideBits = JB_WIDE_BITS;
+  int32_t wide[1 << kWideBits];
 
-  bool build() {
+  bool build(bool is_ac) {
     int code = 0, k = 0;
     for (int len = 1; len <= 16; len++) {
       valptr[len] = k;
@@ -55,16 +60,28 @@ struct HuffTable {
       }
       code <<= 1;
     }
-    // combined code + magnitude lookup (T.81 F.2.2.1 EXTEND folded in)
-    for (int i = 0; i < 512; i++) {
-      fast_ac[i] = 0;
-      const uint16_t f = fast[i];
-      if (!f) continue;
-      const int len = f >> 8, rs = f & 0xff, run = rs >> 4, mag = rs & 15;
-      if (mag == 0 || len + mag > 9) continue;
-      int k = ((i << len) & 511) >> (9 - mag);  // the magnitude bits that follow the code
-      if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;
-      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)((k * 256) + (run * 16) + (len + mag));
+    // combined code + magnitude lookup (T.81 F.2.2.1 EXTEND folded in); AC tables only
+    memset(wide, 0, sizeof wide);
+    code = 0;
+    k = 0;
+    for (int len = 1; is_ac && len <= 16; len++) {
+      for (int i = 0; i < counts[len]; i++, k++, code++) {
+        const int rs = symbols[k], run = rs >> 4, mag = rs & 15;
+        if (len + mag > kWideBits) continue;
+        if (mag == 0 && rs != 0 && rs != 0xf0) continue;  // undefined symbols: general path rejects
+        const int spare = kWideBits - len - mag;
+        for (int m = 0; m < (1 << mag); m++) {
+          int value = m;
+          if (mag && m < (1 << (mag - 1))) value = m - (1 << mag) + 1;
+          int ctl = run;
+          if (rs == 0) ctl = 0x40;
+          else if (rs == 0xf0) ctl = 16 | 0x80;
+          const int32_t e = (int32_t)((uint32_t)(value & 0xffff) << 16) | (ctl << 8) | (len + mag);
+          const int first = ((code << mag) | m) << spare;
+          for (int j = 0; j < (1 << spare); j++) wide[first + j] = e;
+        }
+      }
+      code <<= 1;
     }
     set = true;
     return true;
@@ -205,12 +222,14 @@ inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac
   int k = 1;
   while (k < 64) {
     if (br.nbits < 32) br.refill();
-    const int fa = ac.fast_ac[br.peek(9)];
-    if (fa) {  // code and magnitude resolved by one lookup
-      k += (fa >> 4) & 15;
+    const int32_t fa = ac.wide[br.peek(HuffTable::kWideBits)];
+    if (fa) {  // code and magnitude bits resolved by one lookup
+      const int ctl = (fa >> 8) & 0xff;
+      br.drop(fa & 0xff);
+      if (ctl & 0x40) break;  // EOB
+      k += ctl & 31;
       if (k > 63) return false;  // reference jpeg.cpp:372-376
-      br.drop(fa & 15);
-      out[kZigZag[k++]] = (int16_t)(fa >> 8);
+      if (!(ctl & 0x80)) out[kZigZag[k++]] = (int16_t)(fa >> 16);
       continue;
     }
     const int rs = decode_symbol(br, ac);

@@ -132,7 +132,7 @@ int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
         if (total > 256 || i + total > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
         memcpy(t.symbols, s + i, total);
         i += total;
-        if (!t.build()) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
+        if (!t.build(tc != 0)) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
       }
     } else if (m == 0xdd) {  // DRI, reference jpeg.cpp:289-298
       if (sl != 2) return set_err(e, JB_ERR_FORMAT, "bad DRI segment");

@@ -398,7 +398,7 @@ int run(const uint8_t *d, size_t n, Ext &x, size_t coef_cap_bytes, bool headers_
         if (total > 256 || i + total > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
         memcpy(t.symbols, s + i, (size_t)total);
         i += (size_t)total;
-        if (!t.build()) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
+        if (!t.build(tc != 0)) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
       }
     } else if (m == 0xdd) {  // DRI
       if (sl != 2) return set_err(e, JB_ERR_FORMAT, "bad DRI segment");
