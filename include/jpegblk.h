@@ -125,6 +125,13 @@ int jb_blocks_to_rgb(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef
  * Submissions complete in order. */
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef,
               const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride, int *ticket);
+/* Several images of ONE geometry in one submission (one upload, one launch, one download): for
+ * small images, where the per-submission cost (tens of microseconds of driver calls) would
+ * otherwise bound the rate.  coef = n_images consecutive images (coef_bytes each), qtabs =
+ * n_images x 4*64 uint16, rgb = n_images consecutive images with tightly packed rows.
+ * n_images <= 256 and n_images x (coef_bytes, rgb_bytes) within the context's capacity. */
+int jb_submit_batch(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef,
+                    const uint16_t *qtabs, uint8_t *rgb, int *ticket);
 int jb_wait(jb_ctx *ctx, int ticket);
 /* Non-blocking jb_wait: JB_OK once the submission has completed, JB_PENDING (> 0, not an error)
  * while it is still in flight. */

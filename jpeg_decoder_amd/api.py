@@ -117,6 +117,7 @@ def lib():
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
     L.jb_poll.argtypes = [vp, ctypes.c_int]
+    L.jb_submit_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
     L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
@@ -226,6 +227,17 @@ class Context:
         t = ctypes.c_int(-1)
         _check(lib().jb_submit(self._h, ctypes.byref(desc), _ptr(coef), _ptr(q), _ptr(out),
                                stride or 3 * desc.width, ctypes.byref(t)), self._h)
+        return t.value
+
+    def submit_batch(self, desc, coef, qtabs, out):
+        """jb_submit_batch: n images of one geometry in one submission.  coef int16 [n, blocks, 64],
+        qtabs uint16 [n, 4, 64], out uint8 [n, H, 3*W] (tight rows); all C-contiguous and alive
+        until wait()."""
+        n = coef.shape[0]
+        assert coef.flags.c_contiguous and qtabs.flags.c_contiguous and out.flags.c_contiguous
+        assert qtabs.shape == (n, 4, 64) and out.shape[0] == n
+        t = ctypes.c_int()
+        _check(lib().jb_submit_batch(self._h, ctypes.byref(desc), n, _ptr(coef), _ptr(qtabs), _ptr(out), ctypes.byref(t)), self._h)
         return t.value
 
     def poll(self, ticket):

@@ -140,8 +140,8 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
     Slot &s = ctx->slots[i];
     e = hipMalloc(&s.d_coef, round_up((int64_t)max_coef_bytes, 256));
     if (e == hipSuccess) e = hipMalloc(&s.d_rgb, ctx->rgb_alloc);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.d_q, 768);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_q, 768, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.d_q, 768 * 256);  // tables of up to 256 images
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_q, 768 * 256, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
   }
@@ -253,40 +253,53 @@ void jb_pinned_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
 
-int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
-              uint8_t *rgb, int64_t rgb_stride, int *ticket) {
-  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_submit: ctx is NULL");
-  if (!desc || !coef || !qtabs || !rgb || !ticket) return fail(ctx, JB_ERR_NULL, "jb_submit: NULL pointer");
+namespace {
+
+constexpr int kMaxBatch = 256;  // images per submission (the slot's table block holds that many)
+
+// One submission of the staging ring: n_images images of one geometry, coefficients contiguous
+// (image stride = coef_bytes), tables per image, pixels contiguous with tight rows -- or, for
+// n_images == 1, any row stride.
+int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef, const uint16_t *qtabs,
+                uint8_t *rgb, int64_t rgb_stride, int *ticket) {
   if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
   jb_geometry g;
   int rc = check_desc(ctx, desc, &g);
   if (rc) return rc;
-  if (rgb_stride < 3LL * desc->width) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
+  if (n_images < 1 || n_images > kMaxBatch) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d outside 1..%d", n_images, kMaxBatch);
   const int64_t dev_stride = 3LL * desc->width;  // tight rows on the device (12-byte stores need no alignment)
-  if ((size_t)g.coef_bytes > ctx->max_coef || (size_t)g.rgb_bytes > ctx->rgb_alloc || (size_t)g.rgb_bytes > ctx->max_rgb)
-    return fail(ctx, JB_ERR_CAPACITY, "image %dx%d exceeds the capacity the context was created with", desc->width, desc->height);
+  if (rgb_stride < dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
+  const size_t coef_total = (size_t)g.coef_bytes * (size_t)n_images, rgb_total = (size_t)g.rgb_bytes * (size_t)n_images;
+  if (coef_total > ctx->max_coef || rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)
+    return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
+                desc->width, desc->height);
   DeviceGuard guard(ctx->device);
   Slot &s = ctx->slots[ctx->next_slot];
   if (s.busy) {  // ring full: wait for the oldest submission
     JB_HIP(ctx, hipEventSynchronize(s.done));
     s.busy = false;
   }
-  hipStream_t up = ctx->stream, down = ctx->stream2 ? ctx->stream2 : ctx->stream;
-  rc = jb_resolve_qtabs(desc, qtabs, s.h_q);
-  if (rc) return fail(ctx, rc, "bad quantisation table id");
-  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768, hipMemcpyHostToDevice, up));
-  JB_HIP(ctx, hipMemcpyAsync(s.d_coef, coef, (size_t)g.coef_bytes, hipMemcpyHostToDevice, up));
+  // Groups of small images stay on one stream: they are bound by the rate of submissions, not by
+  // the link, and the cross-stream event costs more than the duplex overlap gives (measured with
+  // 16 host threads on 679x451 images: 14,500 images/s on two streams, 24,800 on one).
+  hipStream_t up = ctx->stream, down = (ctx->stream2 && n_images == 1) ? ctx->stream2 : ctx->stream;
+  for (int i = 0; i < n_images; i++) {
+    rc = jb_resolve_qtabs(desc, qtabs + (size_t)i * 256, s.h_q + (size_t)i * 192);
+    if (rc) return fail(ctx, rc, "bad quantisation table id");
+  }
+  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768u * (size_t)n_images, hipMemcpyHostToDevice, up));
+  JB_HIP(ctx, hipMemcpyAsync(s.d_coef, coef, coef_total, hipMemcpyHostToDevice, up));
   jb_device_batch b;
   memset(&b, 0, sizeof b);
   b.desc = *desc;
-  b.n_images = 1;
+  b.n_images = n_images;
   b.d_coef = (const int16_t *)s.d_coef;
-  b.coef_image_stride = round_up(g.coef_bytes, 16);
+  b.coef_image_stride = g.coef_bytes;  // a multiple of 128
   b.d_qtabs = s.d_q;
-  b.qtab_image_stride = 0;
+  b.qtab_image_stride = n_images > 1 ? 768 : 0;
   b.d_rgb = (uint8_t *)s.d_rgb;
   b.rgb_row_stride = dev_stride;
-  b.rgb_image_stride = dev_stride * desc->height;
+  b.rgb_image_stride = g.rgb_bytes;
   rc = jb_blocks_to_rgb_device(ctx, &b, up);
   if (rc) return rc;
   // the download runs on its own stream, after the kernel: it overlaps the next image's upload
@@ -295,7 +308,7 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
     JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
   }
   if (rgb_stride == dev_stride)
-    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, (size_t)g.rgb_bytes, hipMemcpyDeviceToHost, down));
+    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
   else
     JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
                                  (size_t)desc->height, hipMemcpyDeviceToHost, down));
@@ -306,6 +319,22 @@ int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const
   *ticket = s.ticket;
   ctx->next_slot = (ctx->next_slot + 1) % ctx->n_slots;
   return JB_OK;
+}
+
+}  // namespace
+
+int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
+              uint8_t *rgb, int64_t rgb_stride, int *ticket) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_submit: ctx is NULL");
+  if (!desc || !coef || !qtabs || !rgb || !ticket) return fail(ctx, JB_ERR_NULL, "jb_submit: NULL pointer");
+  return submit_impl(ctx, desc, 1, coef, qtabs, rgb, rgb_stride, ticket);
+}
+
+int jb_submit_batch(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef,
+                    const uint16_t *qtabs, uint8_t *rgb, int *ticket) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_submit_batch: ctx is NULL");
+  if (!desc || !coef || !qtabs || !rgb || !ticket) return fail(ctx, JB_ERR_NULL, "jb_submit_batch: NULL pointer");
+  return submit_impl(ctx, desc, n_images, coef, qtabs, rgb, 3LL * desc->width, ticket);
 }
 
 int jb_wait(jb_ctx *ctx, int ticket) {

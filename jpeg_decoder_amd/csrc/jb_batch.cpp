@@ -191,13 +191,24 @@ void parse_pass(const Run &r, int t, std::vector<Parsed> &parsed, size_t *max_co
   }
 }
 
-// pass 2 (per host thread): decode image k into pinned slot k%2 and submit it; before a slot is
-// reused, the image that used it two steps ago is finished (it has long been through the device
-// by then: one entropy decode takes ~10x its transfers)
+// Small images are submitted in GROUPS: consecutive images of one geometry share one upload, one
+// launch and one download (jb_submit_batch).  A submission costs tens of microseconds of driver
+// calls under the shared mutex; at one submission per 679x451 image that capped the decoder at
+// 11,000 images/s whatever the thread count, five times below what the entropy stage delivers.
+constexpr size_t kGroupBytes = (size_t)16 << 20;  // coefficient bytes per group (and per pinned buffer)
+constexpr int kMaxGroup = 64;
+
+// pass 2 (per host thread): decode a group of images into pinned slot g%2 and submit it; before a
+// slot is reused, the group that used it two steps ago is finished (it has long been through the
+// device by then: entropy decoding takes ~10x the transfers)
 void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, int setup_rc, const std::string &setup_text) {
   const bool use_arena = r.arena && r.arena->base;
   double t_entropy = 0, t_wait = 0;
-  int ticket_of[kSlots] = {-1, -1}, k_of[kSlots] = {-1, -1};
+  struct Group {
+    int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
+  } grp[kSlots];
+  std::vector<uint16_t> qtabs;
+  auto index_of = [&](int k) { return t + k * r.n_threads; };
   auto report = [&](int i, int st, const std::string &text) {
     r.statuses[i] = st;
     if (st == JB_OK) return;
@@ -210,69 +221,117 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     }
   };
   auto finish_slot = [&](int s) {
-    if (k_of[s] < 0) return;
+    Group &g = grp[s];
+    if (g.n == 0) return;
     double a = now_s();
     void *ev;
     {
-      std::lock_guard<std::mutex> g(r.dev->mu);
-      ev = jb_wait_begin_(r.dev->ctx, ticket_of[s]);
+      std::lock_guard<std::mutex> lk(r.dev->mu);
+      ev = jb_wait_begin_(r.dev->ctx, g.ticket);
     }
-    int st = ev ? jb_wait_block_(r.dev->ctx, ev) : JB_OK;
-    const int k = k_of[s], i = t + k * r.n_threads;
-    if (st == JB_OK && !use_arena)  // pinned staging -> the caller's (pageable) buffer
-      memcpy(r.rgb[i], lane->out[s], (size_t)parsed[(size_t)k].geo.rgb_bytes);
+    const int st = ev ? jb_wait_block_(r.dev->ctx, ev) : JB_OK;
+    const std::string text = st == JB_OK ? "" : jb_last_error(nullptr);
+    const size_t rgb_bytes = (size_t)parsed[(size_t)g.first].geo.rgb_bytes;
+    for (int j = 0; j < g.n; j++) {
+      const int i = index_of(g.first + j);
+      if (st == JB_OK && !use_arena)  // pinned staging -> the caller's (pageable) buffer
+        memcpy(r.rgb[i], lane->out[s] + (size_t)j * rgb_bytes, rgb_bytes);
+      report(i, st, text);
+    }
     t_wait += now_s() - a;
-    report(i, st, st == JB_OK ? "" : jb_last_error(nullptr));
-    k_of[s] = -1;
+    g.n = 0;
   };
-  for (size_t k = 0; k < parsed.size(); k++) {
-    Parsed &p = parsed[k];
-    const int i = t + (int)k * r.n_threads, s = (int)(k % kSlots);
-    finish_slot(s);
-    r.rgb[i] = nullptr;
-    r.widths[i] = r.heights[i] = 0;
-    int st = p.status;
-    std::string text = p.error;
-    if (st == JB_OK && setup_rc != JB_OK) {
-      st = setup_rc;
-      text = setup_text;
+  auto same_geometry = [](const Parsed &a, const Parsed &b) {
+    return a.desc.width == b.desc.width && a.desc.height == b.desc.height && a.desc.hs == b.desc.hs &&
+           a.desc.vs == b.desc.vs && a.desc.qtab_id[0] == b.desc.qtab_id[0] &&
+           a.desc.qtab_id[1] == b.desc.qtab_id[1] && a.desc.qtab_id[2] == b.desc.qtab_id[2];
+  };
+  const int n_mine = (int)parsed.size();
+  int k = 0, slot = 0;
+  while (k < n_mine) {
+    Parsed &head = parsed[(size_t)k];
+    r.rgb[index_of(k)] = nullptr;
+    r.widths[index_of(k)] = r.heights[index_of(k)] = 0;
+    if (head.status != JB_OK || setup_rc != JB_OK) {  // rejected in pass 1, or nothing could be set up
+      report(index_of(k), head.status != JB_OK ? head.status : setup_rc, head.status != JB_OK ? head.error : setup_text);
+      head.bytes.clear();
+      head.bytes.shrink_to_fit();
+      k++;
+      continue;
     }
-    if (st == JB_OK) {
+    const int s = slot;
+    finish_slot(s);
+    const size_t coef_bytes = (size_t)head.geo.coef_bytes, rgb_bytes = (size_t)head.geo.rgb_bytes;
+    int room = (int)(lane->cap_coef / coef_bytes);
+    if (room > kMaxGroup) room = kMaxGroup;
+    // entropy-decode consecutive images of the head's geometry into the slot, back to back
+    int n = 0;
+    while (n < room && k + n < n_mine) {
+      Parsed &p = parsed[(size_t)(k + n)];
+      if (n > 0 && (p.status != JB_OK || !same_geometry(head, p))) break;
       double a = now_s();
       // fewer files than host threads: the spare threads split each image's restart intervals
-      st = jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, lane->coef[s], lane->cap_coef,
-                                r.inner_threads);
+      int st = jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs,
+                                    lane->coef[s] + (size_t)n * (coef_bytes / 2), coef_bytes, r.inner_threads);
       t_entropy += now_s() - a;
-      if (st != JB_OK) text = jb_last_error(nullptr);
+      p.bytes.clear();
+      p.bytes.shrink_to_fit();
+      if (st != JB_OK) {  // a corrupt scan: it leaves the group, the group ends before it
+        p.status = st;
+        p.error = jb_last_error(nullptr);
+        if (n == 0) {
+          r.rgb[index_of(k)] = nullptr;
+          report(index_of(k), st, p.error);
+          k++;
+        }
+        break;
+      }
+      n++;
     }
-    if (st == JB_OK) {
-      r.rgb[i] = use_arena ? r.arena->take((size_t)p.geo.rgb_bytes) : alloc_pixels((size_t)p.geo.rgb_bytes);
+    if (n == 0) continue;
+    // where the pixels go
+    uint8_t *dst = use_arena ? r.arena->take((size_t)n * rgb_bytes) : lane->out[s];
+    int st = JB_OK;
+    std::string text;
+    if (!dst) {
+      st = JB_ERR_CAPACITY;
+      text = "output arena exhausted";
+    }
+    qtabs.resize((size_t)n * 256);
+    for (int j = 0; j < n; j++) {
+      const int i = index_of(k + j);
+      Parsed &p = parsed[(size_t)(k + j)];
+      memcpy(&qtabs[(size_t)j * 256], p.qtabs, sizeof p.qtabs);
       r.widths[i] = p.desc.width;
       r.heights[i] = p.desc.height;
-      if (!r.rgb[i]) {
-        st = JB_ERR_CAPACITY;
-        text = use_arena ? "output arena exhausted" : "out of memory";
+      r.rgb[i] = nullptr;
+      if (st == JB_OK) {
+        r.rgb[i] = use_arena ? dst + (size_t)j * rgb_bytes : alloc_pixels(rgb_bytes);
+        if (!r.rgb[i]) {
+          st = JB_ERR_CAPACITY;
+          text = "out of memory";
+        }
       }
     }
-    p.bytes.clear();
-    p.bytes.shrink_to_fit();
     if (st == JB_OK) {
       double a = now_s();
-      // every copy of the submission is pinned <-> device, so this returns at once (unless the
-      // ring is full) and the transfers and the kernel run while this thread decodes its next image
-      std::lock_guard<std::mutex> g(r.dev->mu);
-      st = jb_submit(r.dev->ctx, &p.desc, lane->coef[s], p.qtabs, use_arena ? r.rgb[i] : lane->out[s],
-                     3LL * p.desc.width, &ticket_of[s]);
+      // every copy of the submission is pinned <-> device, so this returns at once and the
+      // transfers and the kernel run while this thread decodes its next group
+      std::lock_guard<std::mutex> lk(r.dev->mu);
+      st = jb_submit_batch(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
       if (st != JB_OK) text = jb_last_error(r.dev->ctx);
       t_wait += now_s() - a;
     }
     if (st != JB_OK) {
-      report(i, st, text);
-      continue;
+      for (int j = 0; j < n; j++) report(index_of(k + j), st, text);
+    } else {
+      grp[s].first = k;
+      grp[s].n = n;
+      slot = (slot + 1) % kSlots;
     }
-    k_of[s] = (int)k;
+    k += n;
   }
-  for (int n = 0; n < kSlots; n++) finish_slot((int)((parsed.size() + (size_t)n) % kSlots));  // oldest first
+  for (int j = 0; j < kSlots; j++) finish_slot((slot + j) % kSlots);  // oldest first
   std::lock_guard<std::mutex> g(r.tot->mu);
   r.tot->t_entropy += t_entropy;
   r.tot->t_device += t_wait;
@@ -401,6 +460,14 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
     tot.t_read += tr[(size_t)t];
   }
   std::string setup_text;
+  // every pinned buffer and ring slot holds one large image or a group of small ones
+  // (rgb_bytes <= coef_bytes for every layout, so one figure serves both)
+  size_t group_bytes = kGroupBytes;
+  if (const char *e = getenv("JPEGBLK_GROUP_MB")) {  // A/B knob: 0 = one image per submission
+    const long mb = atol(e);
+    group_bytes = mb > 0 ? (size_t)mb << 20 : 0;
+  }
+  if (max_coef && max_coef < group_bytes) max_coef = max_rgb = group_bytes;
   int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads) : JB_OK;
   if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
   // pass 2: entropy decoding on the host threads, all submitting to the shared context

@@ -428,3 +428,34 @@ def test_cpp_image_mirror_cli(tmp_path):
     bad.write_bytes(b"not a jpeg")
     r = subprocess.run([cli, str(bad)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "ERROR" in r.stderr
+
+
+@pytest.mark.parametrize("w,h,hs,vs", [(679, 451, 2, 2), (97, 61, 1, 1), (333, 100, 2, 1)])
+def test_submit_batch_small_images(jb, oracle, w, h, hs, vs):
+    """jb_submit_batch: several small images of one geometry, each with its own tables, in one
+    upload + one launch + one download; every image against the oracle; capacity and count
+    limits come back as statuses."""
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    n = 7
+    qid = (0, 1, 2)
+    desc = jb.make_desc(w, h, hs, vs, qid)
+    g = jb.geometry_of(desc)
+    coefs, qs = [], []
+    for i in range(n):
+        q = synth.annex_k_qtabs(35 + 9 * i)
+        q[2] = q[1][::-1]
+        coefs.append(synth.synth_blocks(w, h, hs, vs, i, qtabs=q, qtab_id=qid)[0])
+        qs.append(q)
+    coef, q = np.ascontiguousarray(np.stack(coefs)), np.ascontiguousarray(np.stack(qs))
+    out = np.zeros((n, h, 3 * w), np.uint8)
+    with jb.Context(0, n * g.coef_bytes, n * g.rgb_bytes, 2) as ctx:
+        t = ctx.submit_batch(desc, coef, q, out)
+        ctx.wait(t)
+        for i in range(n):
+            assert np.array_equal(out[i].reshape(h, w, 3), oracle.blocks_to_rgb(odesc(w, h, hs, vs, qid), coefs[i], qs[i])), i
+        # one image more than the context was sized for
+        big = np.ascontiguousarray(np.concatenate([coef, coef[:1]]))
+        with pytest.raises(jb.JbError) as e:
+            ctx.submit_batch(desc, big, np.ascontiguousarray(np.concatenate([q, q[:1]])), np.zeros((n + 1, h, 3 * w), np.uint8))
+        assert e.value.status == -5

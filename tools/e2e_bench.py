@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--source", default="pil", choices=["pil", "writer"])
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--modes", default="malloc,arena")
+    ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
     out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count(),
@@ -115,12 +116,14 @@ def main():
             arena = (args.n * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
             with jb.BatchDecoder(t, 0, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
                 dec.run(paths[:t], keep_pixels=False)          # touch every lane once
-                _, st, tm = dec.run(paths, keep_pixels=False)  # timed: contexts and pinned buffers exist
+                runs = [dec.run(paths, keep_pixels=False) for _ in range(args.repeat)]  # timed: contexts and pinned buffers exist
+                _, st, tm = min(runs, key=lambda x: x[2]["wall_s"])
+                walls = [round(x[2]["wall_s"], 3) for x in runs]
             assert all(s == 0 for s in st), st[:8]
             res.append({"output": mode, "threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
                         "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
                         "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
-                        "wall_s": round(tm["wall_s"], 3),
+                        "wall_s": round(tm["wall_s"], 3), "walls": walls,
                         "device_busy_fraction": round(args.n * k_ms * 1e-3 / tm["wall_s"], 4)})
         out["decode_path"] = res
         # (2) PCIe-inclusive block pipeline from pre-decoded coefficients
