@@ -42,6 +42,7 @@ struct jb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // primary: uploads + kernels of the ring; device-resident launches with a NULL stream
   hipStream_t stream2 = nullptr;  // downloads of the staging ring
+  unsigned n_group_submits = 0;
   size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
   int n_slots = 0;
   Slot slots[64];  // n_slots of them are in use
@@ -279,10 +280,17 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
     JB_HIP(ctx, hipEventSynchronize(s.done));
     s.busy = false;
   }
-  // Groups of small images stay on one stream: they are bound by the rate of submissions, not by
-  // the link, and the cross-stream event costs more than the duplex overlap gives (measured with
-  // 16 host threads on 679x451 images: 14,500 images/s on two streams, 24,800 on one).
-  hipStream_t up = ctx->stream, down = (ctx->stream2 && n_images == 1) ? ctx->stream2 : ctx->stream;
+  // One image: upload + kernel on the primary stream, download on the second (ordered by an
+  // event), so the link runs both ways even with a single submitter.  A group of small images
+  // runs whole on one stream and consecutive groups alternate between the two streams: with many
+  // submitters that overlaps uploads and downloads just as well, without a cross-stream event per
+  // group (measured with 16 host threads on 679x451 images: 14,500 images/s with the event,
+  // 24,700 with every group on one stream, 38,400 alternating).
+  hipStream_t up = ctx->stream, down = ctx->stream2 ? ctx->stream2 : ctx->stream;
+  if (n_images > 1) {
+    if (ctx->stream2 && (ctx->n_group_submits++ & 1u)) up = ctx->stream2;
+    down = up;
+  }
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, qtabs + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
