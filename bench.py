@@ -14,7 +14,7 @@ collective on the data path): weak scaling.
 
 Prints ONE JSON line on rank 0:  metric = Mpixels/s decoded (whole job), plus
   roofline     achieved = algorithmic bytes per launch / mean kernel time (HIP events on the
-               launch stream), against the 8 TB/s HBM3E peak;
+               launch stream around every 8th timed step), against the 8 TB/s HBM3E peak;
   cpu_baseline the reference CPU path (oracle/_ref, the genuine reference compiled in place,
                kind "reference") or, if that build is absent, the C restatement (kind "port"),
                timed on this box's host cores on a bounded sample -- rank 0, N=1 only.
@@ -160,12 +160,19 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events bracket the kernel of every 8th timed step (25 samples of the default 200 steps).
+    # Event packets between back-to-back launches are measurement overhead that the whole-job clock
+    # sees: with a pair around EVERY step ms_per_step was 3.7 % higher (0.2110 vs 0.2035 ms) while the
+    # bracketed kernel time was the same (JB_BENCH_EVENT_EVERY=1 restores that)
+    every = max(1, int(os.environ.get("JB_BENCH_EVENT_EVERY", "8")))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(0, args.steps, every)]
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
+    for k in range(args.steps):
+        if k % every == 0:
+            evs[k // every][0].record(stream)
         step()
-        b.record(stream)
+        if k % every == 0:
+            evs[k // every][1].record(stream)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -203,6 +210,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": jb.lib().jb_kernel_name(desc).decode(), "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_samples": len(kern_ms), "event_every": every,
                          "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
                          "kernel_gpix_s": round(pixels_per_step / (mean_ms * 1e-3) / 1e9, 2)},
         }
