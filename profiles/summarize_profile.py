@@ -59,18 +59,18 @@ def main():
         summary["hbm_read_bytes_per_launch"] = rd
         summary["hbm_write_bytes_per_launch"] = wr
         summary["hbm_bytes_per_launch"] = rd + wr
-    # the default bench command moves 1,207,959,552 algorithmic bytes per launch; other workloads
+    # the default bench command (32 x 4096^2 4:4:4) moves 4,831,838,208 algorithmic bytes per launch; other workloads
     # (JB_BENCH_ARGS in run_profile.sh) state theirs in JB_ALG_BYTES and do not become "latest"
-    alg = int(os.environ.get("JB_ALG_BYTES", "1207959552"))
+    alg = int(os.environ.get("JB_ALG_BYTES", "4831838208"))
     summary["algorithmic_bytes_per_launch"] = alg
-    if "hbm_bytes_per_launch" in summary and alg == 1207959552:
+    if "hbm_bytes_per_launch" in summary and alg == 4831838208:
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json"), "w") as fh:
                 json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": 1207959552}, fh)
+                           "algorithmic_bytes_per_launch": alg}, fh)
             with open(os.path.join(out_dir, "pmc_latest.json"), "w") as fh:
                 json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": 1207959552}, fh)
+                           "algorithmic_bytes_per_launch": alg}, fh)
         except OSError:
             pass
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.json")
