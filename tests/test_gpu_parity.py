@@ -459,3 +459,31 @@ def test_submit_batch_small_images(jb, oracle, w, h, hs, vs):
         with pytest.raises(jb.JbError) as e:
             ctx.submit_batch(desc, big, np.ascontiguousarray(np.concatenate([q, q[:1]])), np.zeros((n + 1, h, 3 * w), np.uint8))
         assert e.value.status == -5
+
+
+def test_huge_image_offsets_beyond_2_31(jb, oracle):
+    """One 32768x24576 4:2:0 image: 2.4 GB of coefficients and 2.4 GB of pixels, so every byte
+    offset inside the image passes 2^31 -- full output against the oracle."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    w, h, hs, vs = 32768, 24576, 2, 2
+    desc = jb.make_desc(w, h, hs, vs)
+    g = jb.geometry_of(desc)
+    assert g.coef_bytes > 2 ** 31 and g.rgb_bytes > 2 ** 31
+    q = synth.annex_k_qtabs(80)
+    pattern = synth.random_blocks(1_000_003, 12, -200, 200)      # a prime count: no alignment with MCU rows
+    coef = np.resize(pattern, (g.n_coded_blocks, 64))
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(dev)
+    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+        coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
+        q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
+        rgb_t = torch.zeros((1, h, 3 * w), dtype=torch.uint8, device=dev)
+        ctx.blocks_to_rgb_device(torch_batch(desc, 1, coef_t, q_t, rgb_t), ts.cuda_stream)
+        torch.cuda.synchronize()
+        got = rgb_t.cpu().numpy()[0].reshape(h, w, 3)
+    del coef_t, rgb_t
+    want = oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=16)
+    assert np.array_equal(got, want)
