@@ -18,9 +18,9 @@
 
 #include "../../include/jpegblk.h"
 
-extern "C" long jw_encode(const int16_t *coef, int width, int height, int hs, int vs, const uint16_t *qtabs,
-                          const int *qtab_id, const uint8_t *dht, int restart_interval, int dqt16, uint8_t *out,
-                          long cap);
+extern "C" long jw_encode_ex(const int16_t *coef, int width, int height, int hs, int vs, const uint16_t *qtabs,
+                             const int *qtab_id, const uint8_t *dht, int restart_interval, int dqt16, int scan_mode,
+                             uint8_t *out, long cap);
 
 // ---- stubs for the parts of the library that need a device ----
 struct jb_ctx;
@@ -45,7 +45,7 @@ static inline uint64_t rnd() {
   return rng_state;
 }
 
-static std::vector<uint8_t> writer_seed(int w, int h, int hs, int vs, int ri, int dqt16) {
+static std::vector<uint8_t> writer_seed(int w, int h, int hs, int vs, int ri, int dqt16, int scan_mode) {
   // Annex K.3 tables are not needed here: any complete prefix code is a legal DHT.  Build simple
   // ones: DC 12 symbols (lengths 2..), AC 162 symbols in run/size order.
   static uint8_t dht[4 * 272];
@@ -82,7 +82,7 @@ static std::vector<uint8_t> writer_seed(int w, int h, int hs, int vs, int ri, in
   for (int i = 0; i < 256; i++) q[i] = (uint16_t)(1 + rnd() % 255);
   const int ids[3] = {0, 1, (int)(rnd() % 2) + 1};
   std::vector<uint8_t> out(2048 + coef.size() * 4);
-  long len = jw_encode(coef.data(), w, h, hs, vs, q, ids, dht, ri, dqt16, out.data(), (long)out.size());
+  long len = jw_encode_ex(coef.data(), w, h, hs, vs, q, ids, dht, ri, dqt16, scan_mode, out.data(), (long)out.size());
   if (len < 0) {
     fprintf(stderr, "writer failed: %ld\n", len);
     exit(2);
@@ -129,9 +129,10 @@ int main(int argc, char **argv) {
     fclose(f);
     if (b.size() <= (1u << 20)) seeds.push_back(std::move(b));  // keep iterations fast
   }
-  const int shapes[][6] = {{33, 17, 1, 1, 0, 0}, {100, 60, 2, 1, 3, 0}, {64, 80, 1, 2, 1, 1}, {130, 70, 2, 2, 5, 0},
-                           {16, 16, 2, 2, 0, 1}, {257, 9, 1, 1, 7, 0}};
-  for (auto &s : shapes) seeds.push_back(writer_seed(s[0], s[1], s[2], s[3], s[4], s[5]));
+  // {w, h, hs, vs, restart interval, 16-bit DQT, scan mode (1 = one scan per component)}
+  const int shapes[][7] = {{33, 17, 1, 1, 0, 0, 0}, {100, 60, 2, 1, 3, 0, 0}, {64, 80, 1, 2, 1, 1, 0}, {130, 70, 2, 2, 5, 0, 0},
+                           {16, 16, 2, 2, 0, 1, 0}, {257, 9, 1, 1, 7, 0, 0}, {97, 61, 2, 2, 4, 0, 1}, {40, 40, 1, 1, 0, 0, 1}};
+  for (auto &s : shapes) seeds.push_back(writer_seed(s[0], s[1], s[2], s[3], s[4], s[5], s[6]));
   // every unmutated seed must decode, or be rejected as unsupported (a progressive file is a fine seed)
   for (auto &s : seeds) {
     jb_image_desc d;
