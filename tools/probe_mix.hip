@@ -50,6 +50,32 @@ __global__ __launch_bounds__(192) void mix_tile(const uint8_t *in, uint8_t *out,
   if (threadIdx.x == 100000) dyn[0] = 1;
 }
 
+// the 4:4:4 shape with an L2 prefetch of a tile `ahead` tiles further on (one dword per 128-B line,
+// issued after this tile's own loads have returned; the result is never used)
+__global__ __launch_bounds__(192) void mix_tile_prefetch(const uint8_t *in, uint8_t *out, long pitch, int tiles_per_row,
+                                                          int ahead, int n_tiles, uint32_t *sink) {
+  extern __shared__ char dyn[];
+  const int t = blockIdx.x;
+  const uint8_t *src = in + (long)t * 24576 + threadIdx.x * 128;
+  u4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = *(const u4 *)(src + i * 16);
+  u4 acc = v[0] ^ v[1] ^ v[2] ^ v[3] ^ v[4] ^ v[5] ^ v[6] ^ v[7];
+  uint32_t pf = 0;
+  if (t + ahead < n_tiles) pf = *(const volatile uint32_t *)(in + (long)(t + ahead) * 24576 + threadIdx.x * 128);
+  const int ty = t / tiles_per_row, tx = t - ty * tiles_per_row;
+  uint8_t *base = out + (long)ty * 8 * pitch + (long)tx * 1536;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int k = 0;
+  for (int it = wave; it < 16; it += 3, k++) {
+    const int row = it >> 1, seg = it & 1;
+    u3 w = u3{acc.x + k, acc.y, acc.z ^ acc.w};
+    __builtin_nontemporal_store(w, (u3 *)(base + (long)row * pitch + seg * 768 + lane * 12));
+  }
+  if (pf == 0x12345678u) sink[0] = pf;  // keeps the prefetch alive
+  if (threadIdx.x == 100000) dyn[0] = 1;
+}
+
 // 4:2:0 shape: 192 threads, 24 KiB read, 24 KiB written as 16 rows x 1536 B (1:2 read:write mix)
 __global__ __launch_bounds__(192) void mix_tile420(const uint8_t *in, uint8_t *out, long pitch, int tiles_per_row) {
   extern __shared__ char dyn[];
@@ -113,6 +139,16 @@ int main() {
   time("tile pattern, nt stores, 24 KiB LDS (6 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 24576>>>(din, dout, 12288, 8); });
   time("tile pattern, nt stores, 40 KiB LDS (4 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 40960>>>(din, dout, 12288, 8); });
   time("tile pattern, nt stores, 64 KiB LDS (2 WG/CU)", [&] { mix_tile<true><<<ntiles, 192, 65536>>>(din, dout, 12288, 8); });
+  {
+    uint32_t *sink;
+    (void)hipMalloc(&sink, 64);
+    time("tile pattern, nt stores, 24 KiB LDS (again)", [&] { mix_tile<true><<<ntiles, 192, 24576>>>(din, dout, 12288, 8); });
+    for (int ahead : {256, 512, 1024, 1536, 3072}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "  + L2 prefetch %d tiles ahead, 24 KiB LDS", ahead);
+      time(nm, [&] { mix_tile_prefetch<<<ntiles, 192, 24576>>>(din, dout, 12288, 8, ahead, ntiles, sink); });
+    }
+  }
   {  // 4:2:0 batch: 8 x 4096^2: 402.7 MB read + 402.7 MB written
     const long r420 = 8L * 4096 * 4096 * 3;
     const int nt420 = r420 / 24576;
