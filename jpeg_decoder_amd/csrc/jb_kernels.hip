@@ -563,7 +563,6 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
         }
         if (!JB_DO_STORE(p)) continue;
         uint32_t w0 = 0, w1 = 0, w2 = 0;
-        if (LINEAR && p.fast_store) pack12_rtz(r, g, b, w0, w1, w2);  // once for both parts
         // part 0: the MCUs before the wrap; part 1 (linear tiling only): the rest, one MCU row down
 #pragma unroll
         for (int part = 0; part < (LINEAR ? 2 : 1); part++) {
@@ -577,7 +576,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
             if (p.fast_store && (part == 0 || rel >= 0)) {
               // whole 4-pixel groups only (a group straddling the image edge is left to the tail
               // below); the descriptor's range check drops the lanes past the part's end
-              if (!LINEAR) pack12_rtz(r, g, b, w0, w1, w2);
+              pack12_rtz(r, g, b, w0, w1, w2);  // (again for the rare second part: cheaper than keeping it live)
               const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (npx >> 2) * 12, 0x00020000);
               __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, LINEAR ? rel * 3 : lane_late * 12, 0, JB_STORE_AUX);
             }
