@@ -11,6 +11,11 @@ while the host Huffman stage is the bottleneck.
 Usage: python tools/e2e_bench.py [--size 1920x1080] [--sub 444|420] [--n 256] [--threads 1,8,16,64]
                                  [--source pil|writer]
   --source writer: files from the build's own baseline writer (tools/jpegwriter) on synthetic blocks
+Several GPUs (host-fed scaling): launch one rank per GPU,
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/e2e_bench.py --images <total> ...
+every rank decodes its shard of the batch (image i -> rank i % N) on its own GPU with its own host
+threads; rank 0 reports the whole-job rate = all images / slowest rank's wall time (gloo for the
+bookkeeping; no collective on the data path).  E2E_SINGLE_DEVICE=1 rehearses that on one GPU.
 """
 import argparse
 import ctypes
@@ -54,13 +59,13 @@ def make_jpegs_writer(n_distinct, w, h, sub, out_dir):
     return paths
 
 
-def kernel_ms_per_image(desc, q, coef):
+def kernel_ms_per_image(desc, q, coef, device=0):
     """Device time of one image's launch with the blocks resident in HBM (torch = plumbing)."""
     import torch
     from jpeg_decoder_amd.api import torch_batch
-    dev = torch.device("cuda:0")
+    dev = torch.device(f"cuda:{device}")
     ts = torch.cuda.Stream(dev)
-    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+    with torch.cuda.stream(ts), jb.Context(device) as ctx:
         coef_t = torch.from_numpy(coef).to(dev).view(1, -1, 64)
         q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
         rgb_t = torch.empty((1, desc.height, 3 * desc.width), dtype=torch.uint8, device=dev)
@@ -88,7 +93,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--sub", default="444")
-    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--n", "--images", dest="n", type=int, default=256)  # --images under torch.distributed.run (--n is ambiguous there)
     ap.add_argument("--threads", default="1,8,16,32,64")
     ap.add_argument("--source", default="pil", choices=["pil", "writer"])
     ap.add_argument("--distinct", type=int, default=8)
@@ -96,36 +101,56 @@ def main():
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = 0 if os.environ.get("E2E_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
     out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count(),
            "cpu_affinity": len(os.sched_getaffinity(0)), "source": args.source}
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d)
-        paths = [distinct[i % len(distinct)] for i in range(args.n)]
+        from jpeg_decoder_amd.shard import shard_images
+        mine = shard_images(args.n, rank, world)           # image i -> rank i % world
+        paths = [distinct[i % len(distinct)] for i in mine]
+        n_mine = len(paths)
         out["file_kbytes_mean"] = round(float(np.mean([os.path.getsize(p) for p in distinct])) / 1024, 1)
         # warm-up (file cache, HIP init)
-        jb.decode_batch(paths[:8], n_threads=4, keep_pixels=False)
+        jb.decode_batch(paths[:8], n_threads=4, device=device, keep_pixels=False)
         res = []
         d0, q0, c0 = jb.entropy_decode(open(distinct[0], "rb").read())
         g0 = jb.geometry_of(d0)
-        k_ms = kernel_ms_per_image(d0, q0, c0)
+        k_ms = kernel_ms_per_image(d0, q0, c0, device)
         out["kernel_ms_per_image"] = round(k_ms, 4)
         del c0
         # two output modes: "malloc" = the default ABI (pixels copied from pinned staging into
         # malloc'ed per-image buffers), "arena" = a pinned output arena owned by the decoder
         for mode, t in [(m, int(x)) for m in args.modes.split(",") for x in args.threads.split(",")]:
-            arena = (args.n * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
-            with jb.BatchDecoder(t, 0, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
+            arena = (n_mine * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
+            with jb.BatchDecoder(t, device, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
                 dec.run(paths[:t], keep_pixels=False)          # touch every lane once
                 runs = [dec.run(paths, keep_pixels=False) for _ in range(args.repeat)]  # timed: contexts and pinned buffers exist
                 _, st, tm = min(runs, key=lambda x: x[2]["wall_s"])
                 walls = [round(x[2]["wall_s"], 3) for x in runs]
             assert all(s == 0 for s in st), st[:8]
+            if dist is not None:   # whole job: all images / the slowest rank
+                import torch
+                tw = torch.tensor([tm["wall_s"]], dtype=torch.float64)
+                dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+                tm = dict(tm, wall_s=float(tw.item()))
             res.append({"output": mode, "threads": t, "images_per_s": round(args.n / tm["wall_s"], 1),
                         "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
                         "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
                         "wall_s": round(tm["wall_s"], 3), "walls": walls,
-                        "device_busy_fraction": round(args.n * k_ms * 1e-3 / tm["wall_s"], 4)})
+                        "device_busy_fraction": round(n_mine * k_ms * 1e-3 / tm["wall_s"], 4), "n_gpus": world})
         out["decode_path"] = res
+        if world > 1:
+            if rank == 0:
+                print(json.dumps(out))
+            dist.destroy_process_group()
+            return
         # (2) PCIe-inclusive block pipeline from pre-decoded coefficients
         desc, q, coef = jb.entropy_decode(open(distinct[0], "rb").read())
         g = jb.geometry_of(desc)
@@ -136,7 +161,7 @@ def main():
             ac[:] = coef.reshape(-1)
             pr, ar = pinned_array(g.rgb_bytes, np.uint8)
             bufs.append((pc, ac, pr, ar))
-        with jb.Context(0, g.coef_bytes, g.rgb_bytes, slots) as ctx:
+        with jb.Context(device, g.coef_bytes, g.rgb_bytes, slots) as ctx:
             n = max(args.n, 64)
             tickets = []
             for warm in (True, False):
