@@ -487,3 +487,42 @@ def test_huge_image_offsets_beyond_2_31(jb, oracle):
     del coef_t, rgb_t
     want = oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=16)
     assert np.array_equal(got, want)
+
+
+def test_contexts_on_concurrent_host_threads(jb, oracle):
+    """SURVEY 8b threading contract: thread-safe per context handle -- four host threads, each
+    with its own context (its own streams and staging ring) on the same GPU, decode different
+    images concurrently; every result against the oracle."""
+    import threading
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    shapes = [(640, 360, 1, 1), (679, 451, 2, 2), (1000, 300, 2, 1), (333, 777, 1, 2)]
+    inputs = [synth.synth_blocks(w, h, hs, vs, 50 + i) for i, (w, h, hs, vs) in enumerate(shapes)]
+    wants = [oracle.blocks_to_rgb(odesc(w, h, hs, vs), c, q, nthreads=4) for (w, h, hs, vs), (c, q) in zip(shapes, inputs)]
+    errors = []
+
+    def work(i):
+        try:
+            w, h, hs, vs = shapes[i]
+            desc = jb.make_desc(w, h, hs, vs)
+            coef, q = inputs[i]
+            with jb.Context.for_image(desc, 0, n_slots=2) as ctx:
+                for rep in range(25):
+                    if rep % 2:
+                        got = ctx.blocks_to_rgb(desc, coef, q)
+                    else:
+                        out = np.zeros((h, 3 * w), np.uint8)
+                        ctx.wait(ctx.submit(desc, coef, q, out))
+                        got = out.reshape(h, w, 3)
+                    if not np.array_equal(got, wants[i]):
+                        errors.append((i, rep))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
