@@ -5,13 +5,16 @@
 // coefficient once and writes every pixel once.
 //
 // Work decomposition (wave64, no MFMA -- this is 8-point butterflies, not a GEMM):
-//   * a workgroup (3 waves, 192 lanes) owns one TILE = a run of 192/NB consecutive MCUs
-//     (NB = hs*vs + 2 coded blocks per MCU): 64 MCUs in 4:4:4, 32 in 4:2:0, 48 in
-//     4:2:2 / 4:4:0 -- always 192 coded blocks = 24 KiB of contiguous int16 coefficients in.
+//   * a workgroup owns one TILE = a run of consecutive MCUs (NB = hs*vs + 2 coded blocks per
+//     MCU), sized so that every wave holds blocks of ONE kind (all luma or all chroma):
+//       4:4:4  192 lanes = 64 MCUs (wave = Y | Cb | Cr)       24 KiB of coefficients, 24 KiB LDS
+//       4:2:0  192 lanes = 32 MCUs (Y | Y | Cb+Cr)            24 KiB, 24 KiB
+//       4:2:2, 4:4:0  256 lanes = 64 MCUs (Y | Y | Cb | Cr)   32 KiB, 32 KiB
+//     always contiguous int16 coefficients in.
 //     Two tilings, chosen by the host (jb_api.cpp) and compiled as separate instantiations:
 //       row-bound (LINEAR=false): tiles never cross an MCU row; the last tile of a row is
 //         partly empty unless mcus_x is a multiple of the tile length (4096/8192 px are);
-//       linear (LINEAR=true): tiles cut the image's MCU stream every 192/NB MCUs regardless of
+//       linear (LINEAR=true): tiles cut the image's MCU stream every tile length regardless of
 //         rows, so only the last tile of an image can be short; a colour segment may then
 //         straddle one row end and is stored in two parts (1920 px: +4.2 %).
 //     blockIdx -> tile is the identity (one compact advancing write window; XCD bands were slower).
@@ -86,8 +89,12 @@ __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(f
 #ifndef JB_SCHED_FENCE
 #define JB_SCHED_FENCE() ((void)0)
 #endif
-constexpr int kTileBlocks = 192;                  // coded blocks per tile = lanes per workgroup
-constexpr int kStripBytes = kTileBlocks * 128;    // 24 KiB: half of the tile's f32 samples
+// Coded blocks per tile = lanes per workgroup: the smallest whole number of MCUs that fills whole
+// waves with ONE component each.  4:4:4 (3 blocks per MCU) and 4:2:0 (6): 192 lanes = 64 / 32 MCUs
+// (in 4:2:0 Cb and Cr share the third wave).  4:2:2 and 4:4:0 (4 blocks per MCU): 256 lanes = 64
+// MCUs = two luma waves, a Cb wave, a Cr wave; with 192 lanes their waves mixed components, which
+// cost a per-lane table select, per-lane strip addressing and a wave per SIMD.
+constexpr int tile_blocks(int hs, int vs) { return hs * vs == 2 ? 256 : 192; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for the
 // global stores of the previous colour phase (vmcnt(0)), putting HBM write latency on the
@@ -201,9 +208,6 @@ __device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-struct __attribute__((packed, aligned(1))) dw3_t {  // 12-byte store at any byte address
-  uint32_t x, y, z;
-};
 
 // Timing experiments (tools/ builds only, never the product): a stage is skipped at run time
 // through a condition the compiler cannot fold, so the code and its registers stay.
@@ -236,7 +240,8 @@ struct __attribute__((packed, aligned(1))) dw3_t {  // 12-byte store at any byte
 // half Cr.  s = sorted index 0..191.
 template <int HS, int VS>
 struct LaneMap {
-  static constexpr int NY = HS * VS, NB = NY + 2, MCUS = kTileBlocks / NB, NYT = NY * MCUS;
+  static constexpr int TB = tile_blocks(HS, VS);
+  static constexpr int NY = HS * VS, NB = NY + 2, MCUS = TB / NB, NYT = NY * MCUS;
   __device__ static __forceinline__ int comp(int s) { return s < NYT ? 0 : (s < NYT + MCUS ? 1 : 2); }
   __device__ static __forceinline__ int mcu(int s) {
     const int c = comp(s);
@@ -255,9 +260,12 @@ struct LaneMap {
 // different tables and selects per lane; kept out of the MIXQ = false instantiation because its
 // register pressure would cost the common case a wave per SIMD.
 template <int HS, int VS, bool MIXQ, bool LINEAR>
-// (forcing 5 waves/SIMD on the 4:2:0 instantiation spills 7 registers and measured 9 % slower)
-__global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_kernel(const JbLaunch p) {
+// (5 waves/SIMD are asked for where that costs no spill: 4:4:4 and 4:4:0; forcing it on 4:2:0 or
+// 4:2:2 spills and measured 9 % slower)
+__global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_tile_kernel(const JbLaunch p) {
   using LM = LaneMap<HS, VS>;
+  constexpr int kTileBlocks = LM::TB;
+  constexpr int kStripBytes = kTileBlocks * 128;  // half of the tile's f32 samples: 24 or 32 KiB
   constexpr int NB = LM::NB, MCUS = LM::MCUS, NYT = LM::NYT;
   constexpr int YW = MCUS * 8 * HS;             // luma strip width in pixels
   constexpr int CW = MCUS * 8;                  // chroma strip width in samples
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
   constexpr int CB_OFF = YROWS * YW * 4;        // byte offsets of the strips in LDS
   constexpr int CR_OFF = CB_OFF + 4 * CW * 4;
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
+  static_assert(NYT % 64 == 0, "whole luma waves: no wave mixes luma and chroma blocks");
   constexpr bool kPermChroma = (VS == 2) && (NYT % 64 == 0);  // 4:2:0: chroma blocks fill a whole wave
   // JB_SPLIT_ROWPASS (experiment): the row passes of register rows 4-7 -- what the second colour
   // phase consumes -- run after the first phase's colour loop instead of before it, so that the
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
   // Two tilings.  Linear (p.linear, the default): a tile is 192/NB consecutive MCUs of the image's
   // MCU stream, whatever MCU rows they fall in -- every tile but the image's last is full for any
   // image width.  Row-bound: a tile is a run of MCUs of ONE MCU row (the last run of a row may be
-  // short); used for very narrow images and for the 4:4:0 layout.
+  // short); used where it leaves no tile ragged, and for very narrow images.
   int my, mx0, nvalid;
   if (LINEAR) {
     const int m0 = rem * MCUS;
@@ -455,8 +464,7 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
   constexpr int TASKS_PER_ROW = YW / 4;
   constexpr int TASKS = YROWS * TASKS_PER_ROW;
   static_assert(TASKS % 64 == 0, "whole wave-iterations");
-  constexpr bool kRowUniform = (TASKS_PER_ROW % 64 == 0);  // a wave-iteration stays within one row
-  const int tile_x0 = mx0 * 8 * HS;
+  static_assert(TASKS_PER_ROW % 64 == 0, "a wave-iteration stays within one strip row");
   uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
   // loop-invariant lane offsets of the colour stage (row-uniform layouts): the lane's 16-B luma
   // chunk within a 64-chunk segment and its chroma chunk, both with the strip swizzle applied
@@ -483,36 +491,20 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
     // strip rows 4*bv..4*bv+3 (VS == 2: the strip holds image rows 4p..4p+3 and 8+4p..8+4p+3);
     // a chroma block contributes the chroma rows those luma rows need: row/VS of each, i.e.
     // rows 2p, 2p+1, 4+2p, 5+2p for VS == 2 (reference jpeg.cpp:518-520).
-    if (VS == 1 || kPermChroma) {
+    static_assert(VS == 1 || kPermChroma, "luma and chroma lanes take the same register rows per phase");
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = phase * 4 + kk;
-        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
-      }
-    } else if (comp_l == 0) {
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = phase * 4 + kk;
-        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = (kk >> 1) * 4 + phase * 2 + (kk & 1);
-        *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
-        *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
-      }
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = phase * 4 + kk;
+      *(float4 *)(dst_lo + kk * pitch) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+      *(float4 *)(dst_hi + kk * pitch) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
     }
     lds_barrier();
 
     // colour transform + store: one lane = 4 adjacent pixels of one row, one wave-iteration =
     // 256 adjacent pixels (768 contiguous output bytes)
     // image row of strip row sr: block-row sr/4, row 4*phase + sr%4 within the block
-    const int y_base = my * 8 * VS + phase * 4;
     for (int it = wave; it < TASKS / 64; it += kTileBlocks / 64) {
-      if (kRowUniform) {
+      {
         // Everything but the data is wave-uniform here: the row, the 256-pixel segment of the row,
         // the output address (a buffer descriptor per segment; lanes address it with the loop-
         // invariant offset lane*12 and the hardware range check drops lanes past the image edge).
@@ -601,52 +593,6 @@ __global__ __launch_bounds__(192, (HS == 1 && VS == 1) ? 5 : 1) void jb_tile_ker
           }
           if (!LINEAR || n_row >= seg_valid) break;  // no second part
         }
-      } else {
-        const int t = it * 64 + lane;
-        const int row = t / TASKS_PER_ROW;
-        const int xq = t - row * TASKS_PER_ROW;
-        const int x = tile_x0 + xq * 4, y = y_base + (row >> 2) * 8 + (row & 3);
-        if (y >= p.height || x >= p.width) continue;
-        const int c = xq ^ ((xq >> 3) & 1);  // swizzled chunk position
-        const float4 Y = *(const float4 *)(lds + row * (YW * 4) + c * 16);
-        float cb[4], cr[4];
-        const int coff = (row / VS) * (CW * 4);
-        if (HS == 1) {
-          const float4 a = *(const float4 *)(lds + CB_OFF + coff + c * 16);
-          const float4 b = *(const float4 *)(lds + CR_OFF + coff + c * 16);
-          cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
-          cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
-        } else {
-          const int cc = xq >> 1;  // chroma chunk holding samples 2*xq, 2*xq+1
-          const int co = (cc ^ ((cc >> 3) & 1)) * 16 + (xq & 1) * 8;
-          const float2 a = *(const float2 *)(lds + CB_OFF + coff + co);
-          const float2 b = *(const float2 *)(lds + CR_OFF + coff + co);
-          cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
-          cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
-        }
-        const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
-        float r[4], g[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
-          g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
-          b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
-        }
-        uint8_t *const o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
-        if (p.fast_store && x + 4 <= p.width) {
-          uint32_t w0, w1, w2;
-          pack12_rtz(r, g, b, w0, w1, w2);
-          *(dw3_t *)o = dw3_t{w0, w1, w2};
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            if (x + i < p.width) {
-              o[i * 3 + 0] = (uint8_t)pack_u8(r[i], 0, 0);
-              o[i * 3 + 1] = (uint8_t)pack_u8(g[i], 0, 0);
-              o[i * 3 + 2] = (uint8_t)pack_u8(b[i], 0, 0);
-            }
-          }
-        }
       }
     }
   }
@@ -656,14 +602,14 @@ template <int HS, int VS>
 static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   using LM = LaneMap<HS, VS>;
   // does any wave hold two components whose tables may differ?
-  constexpr bool kLumaChromaMixed = (LM::NYT % 64 != 0);                      // 4:2:2, 4:4:0
-  constexpr bool kCbCrMixed = (LM::MCUS % 64 != 0);                           // all but 4:4:4
+  constexpr bool kLumaChromaMixed = (LM::NYT % 64 != 0);                      // no layout any more (see tile_blocks)
+  constexpr bool kCbCrMixed = (LM::MCUS % 64 != 0);                           // 4:2:0: Cb and Cr share the third wave
   const bool mixq = kLumaChromaMixed || (kCbCrMixed && !p.chroma_q_equal);
   // the linear tiling is a separate instantiation: where the row-bound tiling leaves no tile
   // ragged (mcus_x a multiple of the tile length, e.g. 4096- and 8192-pixel rows) the simpler
   // row-bound code is 2 % faster
   constexpr bool kCanLinear = ((LM::MCUS * 8 * HS / 4) % 64 == 0);
-  const dim3 grid(p.n_tiles), block(kTileBlocks);
+  const dim3 grid(p.n_tiles), block(LM::TB);
   if (kCanLinear && p.linear) {
     if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, 0, stream, p);
@@ -674,14 +620,13 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-int jbk_mcus_per_tile(int hs, int vs) { return kTileBlocks / (hs * vs + 2); }
+int jbk_mcus_per_tile(int hs, int vs) { return tile_blocks(hs, vs) / (hs * vs + 2); }
 
-// The linear tiling needs the colour stage's row-uniform path (a 256-pixel segment of a strip row
-// is one wave-iteration: 4:4:4, 4:2:2, 4:2:0) and MCU rows at least one segment long, so that a
-// segment wraps to the next MCU row at most once.
+// The linear tiling needs MCU rows at least one 256-pixel segment long, so that a segment wraps to
+// the next MCU row at most once.
 int jbk_linear_ok(int hs, int vs, int mcus_x) {
   const int strip_tasks_per_row = jbk_mcus_per_tile(hs, vs) * 8 * hs / 4;
-  if (strip_tasks_per_row % 64 != 0) return 0;  // 4:4:0
+  if (strip_tasks_per_row % 64 != 0) return 0;  // (no layout: see tile_blocks)
   return mcus_x >= 256 / (8 * hs);
 }
 
@@ -695,9 +640,10 @@ hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
 }
 
 const char *jbk_kernel_name(int hs, int vs) {
-  // <HS, VS, MIXQ, LINEAR>: the last two depend on the tables and the image width
+  // <HS, VS, MIXQ, LINEAR>: LINEAR depends on the image width; MIXQ only exists for 4:2:0 whose
+  // Cb and Cr name different tables
   if (hs == 1 && vs == 1) return "jb_tile_kernel<1, 1, false, *>";
-  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1, true, *>";
-  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2, true, false>";
+  if (hs == 2 && vs == 1) return "jb_tile_kernel<2, 1, false, *>";
+  if (hs == 1 && vs == 2) return "jb_tile_kernel<1, 2, false, *>";
   return "jb_tile_kernel<2, 2, *, *>";
 }
