@@ -206,7 +206,9 @@ void jb_free(void *p);
 int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,
                     uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses, double *times);
 /* The same with the shared context and the per-thread pinned buffers kept across runs (creating
- * them -- page pinning above all -- costs milliseconds per thread).  max_*_bytes pre-size every thread's
+ * them -- page pinning above all -- costs milliseconds per thread).  n_threads is capped at the
+ * CPUs the process may use (affinity mask and cgroup CPU quota): more entropy threads than that
+ * only slow the batch down.  max_*_bytes pre-size every thread's
  * staging (0,0: sized lazily by the first run); a later run with larger images re-sizes. */
 typedef struct jb_batch_decoder jb_batch_decoder;
 int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes, size_t max_rgb_bytes,
