@@ -211,7 +211,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": jb.lib().jb_kernel_name(desc).decode(), "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_samples": len(kern_ms), "event_every": every,
-                         "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
+                         "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_median": round(float(np.median(kern_ms)), 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
                          "kernel_gpix_s": round(pixels_per_step / (mean_ms * 1e-3) / 1e9, 2)},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
