@@ -526,3 +526,25 @@ def test_contexts_on_concurrent_host_threads(jb, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("name", BASELINE_IMAGES)
+def test_reference_with_the_integration_patch(tmp_path, name):
+    """The drop-in itself: the genuine reference (its own marker parser and Huffman decoder,
+    compiled from where it lies by oracle/make_patched_ref.py) with the patch of INTEGRATION.md
+    section 2 in place of dequantize(); inverseDCT(); YCbCrToRGB(); (jpeg.cpp:786-788) must
+    produce the golden pixels through libjpegblk.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(GOLD))
+    exe = os.path.join(root, "oracle", "_ref", "jpeg_patched")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/jpeg_patched not built (needs /root/reference at build time)")
+    pytest.importorskip("PIL")
+    from PIL import Image
+    out = tmp_path / "o.ppm"
+    env = dict(os.environ, JB_DUMP=str(out))
+    env.pop("DISPLAY", None)   # the reference's X11 sink fails headless and the program still exits 0
+    r = subprocess.run([exe, os.path.join(GOLD, "images", name + ".jpg")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    _, _, _, want = load_golden(name)
+    assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), want)
