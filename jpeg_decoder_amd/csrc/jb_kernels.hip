@@ -35,7 +35,8 @@
 //     buffer_store_dwordx3 whose descriptor range check drops lanes past the image edge.
 //     Consecutive lanes are consecutive in the image row: a wave-instruction writes 768
 //     contiguous bytes (six whole 128-B lines).  All per-iteration addressing is scalar.
-//     Two phases keep a workgroup at 24 KiB of LDS = 6 workgroups (18 waves) per CU; the 3
+//     Two phases keep a workgroup at 24 KiB of LDS = 6 workgroups (18 waves) per CU (32 KiB =
+//     5 workgroups of 4 waves for the 256-lane tiles); the 3
 //     workgroup barriers per tile order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
 //
 // Arithmetic is bit-exact with the reference: int32 dequantise (v_mul_i32_i24), the AAN graph
@@ -254,7 +255,7 @@ struct LaneMap {
   }
 };
 
-// One workgroup (192 lanes) per tile.  See the file header for the three stages.
+// One workgroup (192 or 256 lanes) per tile.  See the file header for the three stages.
 // MIXQ = false: every wave dequantises with ONE table (4:4:4 always; 4:2:0 when Cb and Cr name the
 // same table, the usual case).  MIXQ = true: a wave may hold blocks of two components with
 // different tables and selects per lane; kept out of the MIXQ = false instantiation because its
