@@ -46,6 +46,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "jb_kernels.h"
 
@@ -611,12 +612,14 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   // row-bound code is 2 % faster
   constexpr bool kCanLinear = ((LM::MCUS * 8 * HS / 4) % 64 == 0);
   const dim3 grid(p.n_tiles), block(LM::TB);
+  // JPEGBLK_EXTRA_LDS (experiment): unused dynamic LDS per workgroup, to cap workgroups per CU
+  static const unsigned extra_lds = getenv("JPEGBLK_EXTRA_LDS") ? (unsigned)atoi(getenv("JPEGBLK_EXTRA_LDS")) : 0u;
   if (kCanLinear && p.linear) {
-    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, 0, stream, p);
+    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, extra_lds, stream, p);
+    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, extra_lds, stream, p);
   } else {
-    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, false>), grid, block, 0, stream, p);
+    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, false>), grid, block, extra_lds, stream, p);
+    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, false>), grid, block, extra_lds, stream, p);
   }
   return hipGetLastError();
 }
