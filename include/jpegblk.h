@@ -102,6 +102,14 @@ int jb_geometry_of(const jb_image_desc *desc, jb_geometry *out);
 int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, int n_slots,
                   jb_ctx **out);
 void jb_ctx_destroy(jb_ctx *ctx);
+/* Grow the staging ring of a context to images of up to (max_coef_bytes, max_rgb_bytes); a
+ * context created with (0,0) gets its ring (of the depth given at creation) here.  Waits for
+ * everything in flight first; never shrinks.  jb_decode_file / jb_decode_memory call this with the
+ * parsed frame's sizes, so a context need not know its largest image in advance (the reference's
+ * Image allocates `new MCU[...]` per file from the SOF sizes, jpeg.cpp:407). */
+int jb_ctx_reserve(jb_ctx *ctx, size_t max_coef_bytes, size_t max_rgb_bytes);
+/* The HIP device a context lives on. */
+int jb_ctx_device(const jb_ctx *ctx);
 /* Text of the last error on this context (or of the last context-less error on this thread
  * when ctx is NULL).  Never NULL. */
 const char *jb_last_error(const jb_ctx *ctx);
@@ -137,8 +145,19 @@ int jb_wait(jb_ctx *ctx, int ticket);
  * while it is still in flight. */
 #define JB_PENDING 1
 int jb_poll(jb_ctx *ctx, int ticket);
+/* Pinned host memory for the coefficient / pixel buffers handed to jb_submit (the reference's
+ * `new MCU[...]`, jpeg.cpp:407, is the buffer this replaces).  Pinned memory is pinned against a
+ * device and placed on the host NUMA node closest to it: jb_pinned_alloc_on names the device --
+ * use it with the device of the context the buffer will be submitted to, above all from threads
+ * that never called hipSetDevice (their current device is 0 whatever GPU the process drives).
+ * jb_pinned_alloc = jb_pinned_alloc_on(the calling thread's current device). */
+void *jb_pinned_alloc_on(int device_id, size_t bytes);
 void *jb_pinned_alloc(size_t bytes);
 void jb_pinned_free(void *p);
+/* Host NUMA node closest to a device (>= 0), or a negative jb_status when unknown.  One process
+ * per GPU (the reference decodes one image per process, jpeg.cpp:916-929): a rank keeps its
+ * entropy threads and its staging on this node. */
+int jb_device_numa_node(int device_id);
 
 /* ---- the seam: device-resident buffers (what bench.py and multi-image batches use) ------ */
 /* A batch = n_images images of identical geometry, processed by ONE kernel launch on `stream`
@@ -193,6 +212,10 @@ int jb_decode_file(jb_ctx *ctx, const char *path, uint8_t **rgb, int32_t *width,
 int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_t **rgb,
                      int32_t *width, int32_t *height);
 void jb_free(void *p);
+/* Frame descriptor (sampling factors, table ids) of the last image jb_decode_file / jb_decode_memory
+ * decoded on this context -- with jb_geometry_of it yields the reference's public fields
+ * mcuWidthReal / mcuHeightReal (jpeg.cpp:794-795, computed at :118-125). */
+int jb_ctx_last_desc(const jb_ctx *ctx, jb_image_desc *out);
 
 /* Batch of files: the multi-image form of decode(path) (BASELINE.json configs 4-5: "host Huffman
  * on all cores overlapped with device IDCT").  `n_threads` host threads each own a context on
@@ -216,6 +239,16 @@ int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
 int jb_batch_decoder_run(jb_batch_decoder *dec, const char *const *paths, int n_paths, uint8_t **rgb,
                          int32_t *widths, int32_t *heights, int *statuses, double *times);
 void jb_batch_decoder_destroy(jb_batch_decoder *dec);
+/* One decoder over SEVERAL devices of the node (BASELINE.json configs 4-5 as ONE call; images are
+ * independent -- reference jpeg.cpp:574-589 touches each block on its own, jpeg.cpp:916-929 decodes
+ * one image per process -- so file i goes to device_ids[i % n_devices], no data crosses devices).
+ * Per listed device: one shared-context staging ring and an equal share of the n_threads host
+ * threads, each bound to the CPUs of that device's NUMA node with its pinned staging allocated
+ * there.  A device may be listed more than once (two rings on one GPU).  The handle is used with
+ * jb_batch_decoder_run / _set_arena / _destroy like a single-device one; an arena is one pinned
+ * allocation shared by all devices. */
+int jb_batch_decoder_create_multi(const int *device_ids, int n_devices, int n_threads, size_t max_coef_bytes,
+                                  size_t max_rgb_bytes, jb_batch_decoder **out);
 /* Optional pinned output arena owned by the decoder (bytes = 0 releases it).  With an arena,
  * jb_batch_decoder_run places every decoded image in it -- rgb[i] points INTO the arena: do not
  * jb_free it; it stays valid until the next run, set_arena or destroy -- and the device writes the

@@ -23,11 +23,13 @@ struct Error : std::runtime_error {
 };
 
 // One HIP device + stream + staging ring (jb_ctx).  Share one Context between Images that are
-// decoded from the same host thread; use one Context per thread / per GPU otherwise.
+// decoded from the same host thread; use one Context per thread / per GPU otherwise.  By default
+// the staging ring is sized lazily from the first frame decoded (jb_ctx_reserve) and grows with
+// larger ones -- as the reference sizes `new MCU[...]` per file (jpeg.cpp:407) -- so a thumbnail
+// costs a thumbnail's worth of device memory and a 65535x65535 frame still decodes.
 class Context {
  public:
-  explicit Context(int device = 0, size_t max_coef_bytes = 256u << 20, size_t max_rgb_bytes = 256u << 20,
-                   int n_slots = 2) {
+  explicit Context(int device = 0, size_t max_coef_bytes = 0, size_t max_rgb_bytes = 0, int n_slots = 2) {
     int rc = jb_ctx_create(device, max_coef_bytes, max_rgb_bytes, n_slots, &ctx_);
     if (rc) throw Error(rc, jb_last_error(nullptr));
   }
@@ -65,8 +67,14 @@ class Image {
     if (rc) throw Error(rc, jb_last_error(ctx_->get()));
     image_width = w;
     image_height = h;
-    mcuWidthReal = (w + 7) / 8;   // padding to the sampling factor (jpeg.cpp:118-125) is internal to the
-    mcuHeightReal = (h + 7) / 8;  // pipeline now: the RGB buffer is already cropped to width x height
+    // (w+7)/8 rounded up to the luma sampling factor, as read_sof computes them (jpeg.cpp:118-125)
+    jb_image_desc d;
+    jb_geometry g;
+    rc = jb_ctx_last_desc(ctx_->get(), &d);
+    if (!rc) rc = jb_geometry_of(&d, &g);
+    if (rc) throw Error(rc, jb_last_error(nullptr));
+    mcuWidthReal = g.mcu_w_real;
+    mcuHeightReal = g.mcu_h_real;
   }
 
   // The decoded picture: image_height rows of image_width R,G,B byte triples.  Equals

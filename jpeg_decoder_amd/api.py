@@ -99,6 +99,11 @@ def lib():
     L.jb_wait.argtypes = [vp, ctypes.c_int]
     L.jb_pinned_alloc.argtypes = [ctypes.c_size_t]
     L.jb_pinned_alloc.restype = vp
+    L.jb_pinned_alloc_on.argtypes = [ctypes.c_int, ctypes.c_size_t]
+    L.jb_pinned_alloc_on.restype = vp
+    L.jb_device_numa_node.argtypes = [ctypes.c_int]
+    L.jb_ctx_reserve.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t]
+    L.jb_ctx_device.argtypes = [vp]
     L.jb_pinned_free.argtypes = [vp]
     L.jb_pinned_free.restype = None
     L.jb_blocks_to_rgb_device.argtypes = [vp, ctypes.POINTER(DeviceBatch), vp]
@@ -113,6 +118,8 @@ def lib():
                                   ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     L.jb_batch_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.jb_batch_decoder_create_multi.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                                ctypes.c_size_t, ctypes.POINTER(vp)]
     L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
@@ -192,6 +199,14 @@ class Context:
         if self._h:
             lib().jb_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def reserve(self, max_coef_bytes, max_rgb_bytes):
+        """jb_ctx_reserve: grow (or create) the staging ring."""
+        _check(lib().jb_ctx_reserve(self._h, max_coef_bytes, max_rgb_bytes), self._h)
+
+    @property
+    def device(self):
+        return lib().jb_ctx_device(self._h)
 
     def __enter__(self):
         return self
@@ -280,11 +295,17 @@ class Context:
 
 
 class BatchDecoder:
-    """jb_batch_decoder: n_threads host lanes (context + pinned buffers each), reusable."""
+    """jb_batch_decoder: n_threads host lanes (pinned buffers each) feeding one shared context per
+    device, reusable.  devices=[...] (jb_batch_decoder_create_multi): one decoder over several
+    devices, file i -> devices[i % len(devices)], the host threads split evenly."""
 
-    def __init__(self, n_threads=8, device=0, max_coef_bytes=0, max_rgb_bytes=0, arena_bytes=0):
+    def __init__(self, n_threads=8, device=0, max_coef_bytes=0, max_rgb_bytes=0, arena_bytes=0, devices=None):
         self._h = ctypes.c_void_p()
-        _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
+        if devices is not None:
+            ids = (ctypes.c_int * len(devices))(*devices)
+            _check(lib().jb_batch_decoder_create_multi(ids, len(devices), n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
+        else:
+            _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
         self._arena = False
         if arena_bytes:
             _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))

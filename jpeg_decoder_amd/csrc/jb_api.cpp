@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <sched.h>
+
 #include "../../include/jpegblk.h"
 #include "jb_kernels.h"
 
@@ -45,9 +47,11 @@ struct jb_ctx {
   unsigned n_group_submits = 0;
   size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
   int n_slots = 0;
+  int n_slots_req = 1;  // ring depth asked for at creation (used when jb_ctx_reserve builds the ring later)
   Slot slots[64];  // n_slots of them are in use
   int next_slot = 0;
   int next_ticket = 1;
+  jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
 };
 
@@ -84,6 +88,27 @@ struct DeviceGuard {
     if (changed) (void)hipSetDevice(prev);
   }
 };
+
+// The staging ring of a context (device coefficient / pixel buffers, a pinned table block and two
+// events per slot, plus the download stream), sized from ctx->max_coef / ctx->rgb_alloc.  The
+// caller holds a DeviceGuard on ctx->device, so the pinned table blocks are pinned against THAT
+// device (and land on its NUMA node), not against whatever device the calling thread had current.
+hipError_t build_ring(jb_ctx *ctx) {
+  hipError_t e = hipSuccess;
+  // JPEGBLK_SINGLE_STREAM=1 (A/B knob): downloads on the upload stream as well
+  const char *single = getenv("JPEGBLK_SINGLE_STREAM");
+  if (!ctx->stream2 && !(single && single[0] == '1')) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
+    Slot &s = ctx->slots[i];
+    e = hipMalloc(&s.d_coef, round_up((int64_t)ctx->max_coef, 256));
+    if (e == hipSuccess) e = hipMalloc(&s.d_rgb, ctx->rgb_alloc);
+    if (e == hipSuccess && !s.d_q) e = hipMalloc((void **)&s.d_q, 768 * 256);  // tables of up to 256 images
+    if (e == hipSuccess && !s.h_q) e = hipHostMalloc((void **)&s.h_q, 768 * 256, hipHostMallocDefault);
+    if (e == hipSuccess && !s.done) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    if (e == hipSuccess && !s.computed) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
+  }
+  return e;
+}
 
 int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
   int rc = jb_geometry_of(d, g);
@@ -130,22 +155,11 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   ctx->max_rgb = max_rgb_bytes;
   ctx->rgb_alloc = max_rgb_bytes ? (size_t)round_up((int64_t)max_rgb_bytes, 256) : 0;  // device rows are tightly packed
   ctx->n_slots = max_coef_bytes ? n_slots : 0;
+  ctx->n_slots_req = n_slots;
   DeviceGuard guard(device_id);
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  // JPEGBLK_SINGLE_STREAM=1 (A/B knob): downloads on the upload stream as well
-  const char *single = getenv("JPEGBLK_SINGLE_STREAM");
-  if (e == hipSuccess && ctx->n_slots > 0 && !(single && single[0] == '1'))
-    e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-  for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
-    Slot &s = ctx->slots[i];
-    e = hipMalloc(&s.d_coef, round_up((int64_t)max_coef_bytes, 256));
-    if (e == hipSuccess) e = hipMalloc(&s.d_rgb, ctx->rgb_alloc);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.d_q, 768 * 256);  // tables of up to 256 images
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_q, 768 * 256, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
-  }
+  if (e == hipSuccess && ctx->n_slots > 0) e = build_ring(ctx);
   if (e != hipSuccess) {
     int rc = fail(nullptr, JB_ERR_HIP, "jb_ctx_create: %s", hipGetErrorString(e));
     jb_ctx_destroy(ctx);
@@ -240,14 +254,98 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   return JB_OK;
 }
 
-void *jb_pinned_alloc(size_t bytes) {
-  void *p = nullptr;
-  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+int jb_ctx_device(const jb_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int jb_ctx_last_desc(const jb_ctx *ctx, jb_image_desc *out) {
+  if (!ctx || !out) return fail(nullptr, JB_ERR_NULL, "jb_ctx_last_desc: NULL pointer");
+  if (ctx->last_desc.width == 0) return fail(nullptr, JB_ERR_STATE, "jb_ctx_last_desc: nothing decoded on this context yet");
+  *out = ctx->last_desc;
+  return JB_OK;
+}
+
+int jb_ctx_reserve(jb_ctx *ctx, size_t max_coef_bytes, size_t max_rgb_bytes) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_reserve: ctx is NULL");
+  if (max_coef_bytes == 0 || max_rgb_bytes == 0) return fail(ctx, JB_ERR_CAPACITY, "jb_ctx_reserve: sizes must be non-zero");
+  if (ctx->n_slots > 0 && max_coef_bytes <= ctx->max_coef && max_rgb_bytes <= ctx->max_rgb) return JB_OK;
+  DeviceGuard guard(ctx->device);
+  // nothing may be in flight while the slots' buffers are replaced
+  JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  if (max_coef_bytes < ctx->max_coef) max_coef_bytes = ctx->max_coef;
+  if (max_rgb_bytes < ctx->max_rgb) max_rgb_bytes = ctx->max_rgb;
+  const int n = ctx->n_slots > 0 ? ctx->n_slots : ctx->n_slots_req;
+  for (int i = 0; i < n; i++) {
+    Slot &s = ctx->slots[i];
+    s.busy = false;
+    if (s.d_coef) (void)hipFree(s.d_coef);
+    if (s.d_rgb) (void)hipFree(s.d_rgb);
+    s.d_coef = s.d_rgb = nullptr;
+  }
+  ctx->max_coef = max_coef_bytes;
+  ctx->max_rgb = max_rgb_bytes;
+  ctx->rgb_alloc = (size_t)round_up((int64_t)max_rgb_bytes, 256);
+  ctx->n_slots = n;
+  hipError_t e = build_ring(ctx);
   if (e != hipSuccess) {
-    fail(nullptr, JB_ERR_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    ctx->n_slots = 0;  // a half-built ring is not used; jb_ctx_destroy releases what exists
+    ctx->max_coef = ctx->max_rgb = ctx->rgb_alloc = 0;
+    return fail(ctx, JB_ERR_HIP, "jb_ctx_reserve(%zu, %zu): %s", max_coef_bytes, max_rgb_bytes, hipGetErrorString(e));
+  }
+  return JB_OK;
+}
+
+// Pinned host memory is pinned AGAINST a device: hipHostMalloc registers the pages with the
+// calling thread's current device and (ROCm's default policy) takes them from the host NUMA node
+// closest to that device.  Under one rank per GPU with every GPU visible, a fresh std::thread's
+// current device is 0 -- so the device is always named explicitly here.
+void *jb_pinned_alloc_on(int device_id, size_t bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+    fail(nullptr, JB_ERR_HIP, "jb_pinned_alloc_on: device %d not available (%d HIP devices visible)", device_id, ndev);
+    return nullptr;
+  }
+  DeviceGuard guard(device_id);
+  void *p = nullptr;
+  // portable: every device of the process may copy to / from it (a multi-device decoder's shared arena)
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+  if (e != hipSuccess) {
+    fail(nullptr, JB_ERR_HIP, "hipHostMalloc(%zu) on device %d: %s", bytes, device_id, hipGetErrorString(e));
     return nullptr;
   }
   return p;
+}
+
+void *jb_pinned_alloc(size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    fail(nullptr, JB_ERR_HIP, "jb_pinned_alloc: no usable HIP device");
+    return nullptr;
+  }
+  return jb_pinned_alloc_on(dev, bytes);
+}
+
+int jb_device_numa_node(int device_id) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess) return fail(nullptr, JB_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, JB_ERR_HIP, "device %d not available (%d HIP devices visible)", device_id, ndev);
+  int node = -1;
+  if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device_id) == hipSuccess && node >= 0) return node;
+  // fallback: the PCI function's numa_node in sysfs
+  char bdf[32] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device_id) == hipSuccess) {
+    for (char *c = bdf; *c; c++)
+      if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[96];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    if (FILE *f = fopen(path, "r")) {
+      int v = -1;
+      if (fscanf(f, "%d", &v) != 1) v = -1;
+      fclose(f);
+      if (v >= 0) return v;
+    }
+  }
+  return fail(nullptr, JB_ERR_STATE, "NUMA node of device %d unknown", device_id);
 }
 
 void jb_pinned_free(void *p) {
@@ -454,6 +552,48 @@ int jb_wait_block_(jb_ctx *ctx, void *event) {
   if (e != hipSuccess) return fail(nullptr, JB_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
   return JB_OK;
 }
+
+// Bind the calling host thread to the CPUs of the NUMA node closest to `device` (intersected with
+// the CPUs the thread may already use; nothing changes when the node is unknown, the intersection
+// is empty, or JPEGBLK_NUMA=0).  The entropy threads of one rank then read their files, decode and
+// write their pinned staging on the socket their GPU hangs off.  Returns the CPUs in the new mask,
+// 0 = left as it was.
+int jb_bind_thread_near_device_(int device) {
+  const char *knob = getenv("JPEGBLK_NUMA");
+  if (knob && knob[0] == '0') return 0;
+  const int node = jb_device_numa_node(device);
+  if (node < 0) return 0;
+  char path[96];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return 0;
+  char list[4096] = {0};
+  const bool got = fgets(list, sizeof list, f) != nullptr;
+  fclose(f);
+  if (!got) return 0;
+  cpu_set_t cur, want;
+  if (sched_getaffinity(0, sizeof cur, &cur) != 0) return 0;
+  CPU_ZERO(&want);
+  int n = 0;
+  for (char *p = list; *p;) {  // "0-15,128-143"
+    char *end;
+    long a = strtol(p, &end, 10), b = a;
+    if (end == p) break;
+    if (*end == '-') b = strtol(end + 1, &end, 10);
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && CPU_ISSET((int)c, &cur)) {
+        CPU_SET((int)c, &want);
+        n++;
+      }
+    p = (*end == ',') ? end + 1 : end;
+    if (*end != ',') break;
+  }
+  if (n == 0 || n == CPU_COUNT(&cur)) return 0;  // nothing to narrow
+  if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
+  return n;
+}
+
+void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d) { ctx->last_desc = *d; }
 
 // used by jb_frontend.cpp to report through the same channel
 int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%s", msg); }

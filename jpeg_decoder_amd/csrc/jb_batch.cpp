@@ -33,6 +33,8 @@ int jb_fail_(jb_ctx *ctx, int code, const char *msg);
 void *jb_wait_begin_(jb_ctx *ctx, int ticket);
 // ... and the blocking part, without the lock
 int jb_wait_block_(jb_ctx *ctx, void *event);
+// binds the calling thread to the CPUs of the NUMA node closest to a device (jb_api.cpp)
+int jb_bind_thread_near_device_(int device);
 
 namespace {
 
@@ -119,17 +121,19 @@ struct Lane {
   size_t cap_coef = 0, cap_rgb = 0;
   bool has_out = false;
 
-  int ensure(size_t need_coef, size_t need_rgb, bool with_out) {
+  // `device`: the GPU this lane's decoder drives -- the buffers are pinned against it and come from
+  // its NUMA node, whatever device the allocating thread has current (a fresh std::thread: 0)
+  int ensure(int device, size_t need_coef, size_t need_rgb, bool with_out) {
     if (coef[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out)) return JB_OK;
     if (need_coef < cap_coef) need_coef = cap_coef;
     if (need_rgb < cap_rgb) need_rgb = cap_rgb;
     release();
     int rc = JB_OK;
     for (int s = 0; s < kSlots && rc == JB_OK; s++) {
-      coef[s] = (int16_t *)jb_pinned_alloc(need_coef);
+      coef[s] = (int16_t *)jb_pinned_alloc_on(device, need_coef);
       if (!coef[s]) rc = JB_ERR_HIP;
       if (with_out && rc == JB_OK) {
-        out[s] = (uint8_t *)jb_pinned_alloc(need_rgb);
+        out[s] = (uint8_t *)jb_pinned_alloc_on(device, need_rgb);
         if (!out[s]) rc = JB_ERR_HIP;
       }
     }
@@ -187,6 +191,7 @@ struct Totals {
 };
 
 struct Run {
+  int device;
   const char *const *paths;
   int n_paths, n_threads, inner_threads;
   uint8_t **rgb;
@@ -200,6 +205,7 @@ struct Run {
 // pass 1 (per host thread): read its files and parse the headers, so that the buffers can be
 // sized once for the whole batch
 void parse_pass(const Run &r, int t, std::vector<Parsed> &parsed, size_t *max_coef, size_t *max_rgb, double *t_read) {
+  jb_bind_thread_near_device_(r.device);  // the file bytes are first touched here: keep them on the GPU's node
   for (size_t k = 0; k < parsed.size(); k++) {
     const int i = t + (int)k * r.n_threads;
     Parsed &p = parsed[k];
@@ -233,6 +239,7 @@ constexpr int kMaxGroup = 64;
 // slot is reused, the group that used it two steps ago is finished (it has long been through the
 // device by then: entropy decoding takes ~10x the transfers)
 void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, int setup_rc, const std::string &setup_text) {
+  jb_bind_thread_near_device_(r.device);
   const bool use_arena = r.arena && r.arena->base;
   double t_entropy = 0, t_wait = 0;
   struct Group {
@@ -293,8 +300,13 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     const int s = slot;
     finish_slot(s);
     const size_t coef_bytes = (size_t)head.geo.coef_bytes, rgb_bytes = (size_t)head.geo.rgb_bytes;
-    int room = (int)(lane->cap_coef / coef_bytes);
+    // a group must fit the coefficient AND the pixel capacity (pinned lane buffers and ring slots are
+    // sized from the batch's largest image: rgb/coef is 0.5 for 4:4:4 and 1.0 for 4:2:0, so many
+    // small 4:2:0 images next to one large 4:4:4 image are bounded by the pixel side)
+    size_t room_c = lane->cap_coef / coef_bytes, room_p = lane->cap_rgb / rgb_bytes;
+    int room = (int)(room_c < room_p ? room_c : room_p);
     if (room > kMaxGroup) room = kMaxGroup;
+    if (room < 1) room = 1;  // (cannot happen: the capacities cover the largest single image)
     // entropy-decode consecutive images of the head's geometry into the slot, back to back
     int n = 0;
     while (n < room && k + n < n_mine) {
@@ -373,9 +385,13 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
 struct jb_batch_decoder {
   int device = 0;
   std::vector<Lane> lanes;
-  Arena arena;
-  jb_ctx *ctx = nullptr;  // the one context the device thread drives
+  Arena own_arena;
+  Arena *arena = &own_arena;  // a part of a multi-device decoder points at its parent's arena
+  jb_ctx *ctx = nullptr;      // the one context all host threads of this device submit to
   size_t ctx_coef = 0, ctx_rgb = 0;
+  // multi-device decoder (jb_batch_decoder_create_multi): one single-device decoder per listed
+  // device; this object then only deals the files out and owns the shared arena
+  std::vector<jb_batch_decoder *> parts;
 
   int ensure_ctx(size_t need_coef, size_t need_rgb) {
     if (ctx && need_coef <= ctx_coef && need_rgb <= ctx_rgb) return JB_OK;
@@ -401,11 +417,12 @@ struct jb_batch_decoder {
   int ensure_all(size_t need_coef, size_t need_rgb, int n_lanes) {
     int rc = ensure_ctx(need_coef, need_rgb);
     if (rc != JB_OK) return rc;
-    const bool with_out = !arena.base;
+    const bool with_out = !arena->base;
     std::vector<std::thread> th;
     std::vector<int> rcs((size_t)n_lanes, JB_OK);
+    const int dev = device;
     for (int i = 0; i < n_lanes; i++)
-      th.emplace_back([&, i] { rcs[(size_t)i] = lanes[(size_t)i].ensure(need_coef, need_rgb, with_out); });
+      th.emplace_back([&, i] { rcs[(size_t)i] = lanes[(size_t)i].ensure(dev, need_coef, need_rgb, with_out); });
     for (auto &x : th) x.join();
     for (int r : rcs)
       if (r != JB_OK) return jb_fail_(nullptr, r, "pinned host allocation failed");
@@ -413,15 +430,18 @@ struct jb_batch_decoder {
   }
 };
 
-extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
-                                       size_t max_rgb_bytes, jb_batch_decoder **out) {
-  if (!out) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create: out is NULL");
-  *out = nullptr;
+namespace {
+
+int clamp_threads(int n_threads) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   // no more entropy threads than CPUs this process may use (JPEGBLK_OVERSUBSCRIBE=1 lifts that)
   const char *over = getenv("JPEGBLK_OVERSUBSCRIBE");
   if (!(over && over[0] == '1') && n_threads > available_cpus()) n_threads = available_cpus();
+  return n_threads;
+}
+
+int create_single(int device_id, int n_threads, size_t max_coef_bytes, size_t max_rgb_bytes, jb_batch_decoder **out) {
   jb_batch_decoder *d = new jb_batch_decoder();
   d->device = device_id;
   d->lanes.resize((size_t)n_threads);
@@ -438,42 +458,16 @@ extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_
   return JB_OK;
 }
 
-extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
-  if (!d) return;
-  for (auto &l : d->lanes) l.release();
-  jb_ctx_destroy(d->ctx);
-  jb_pinned_free(d->arena.base);
-  delete d;
-}
-
-extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
-  if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_arena: decoder is NULL");
-  jb_pinned_free(d->arena.base);
-  d->arena.base = nullptr;
-  d->arena.bytes = 0;
-  d->arena.used = 0;
-  if (bytes) {
-    d->arena.base = (uint8_t *)jb_pinned_alloc(bytes);
-    if (!d->arena.base) return jb_fail_(nullptr, JB_ERR_HIP, "jb_batch_decoder_set_arena: pinned allocation failed");
-    d->arena.bytes = bytes;
-    for (auto &l : d->lanes) l.drop_out();  // no pixel staging while an arena takes the pixels
-  }
-  return JB_OK;
-}
-
-extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *paths, int n_paths,
-                                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
-                                    double *times) {
-  if (!d || !paths || !rgb || !widths || !heights || !statuses)
-    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_run: NULL pointer");
-  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
+// one device's share of a run; `top` = this decoder owns the arena (and recycles it)
+int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8_t **rgb, int32_t *widths,
+               int32_t *heights, int *statuses, double *times, bool top) {
   int n_threads = (int)d->lanes.size();
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   Shared dev;
-  Run r{paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
-        rgb, widths, heights, statuses, &d->arena, &dev, &tot};
-  d->arena.used = 0;  // the previous run's images are released
+  Run r{d->device, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
+        rgb, widths, heights, statuses, d->arena, &dev, &tot};
+  if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
   // pass 1: headers, in parallel
   std::vector<std::vector<Parsed>> parsed((size_t)n_threads);
@@ -494,14 +488,15 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
     tot.t_read += tr[(size_t)t];
   }
   std::string setup_text;
-  // every pinned buffer and ring slot holds one large image or a group of small ones
-  // (rgb_bytes <= coef_bytes for every layout, so one figure serves both)
+  // every pinned buffer and ring slot holds one large image or a group of small ones: the group
+  // figure bounds the coefficient and the pixel side alike (rgb_bytes <= coef_bytes in every layout)
   size_t group_bytes = kGroupBytes;
   if (const char *e = getenv("JPEGBLK_GROUP_MB")) {  // A/B knob: 0 = one image per submission
     const long mb = atol(e);
     group_bytes = mb > 0 ? (size_t)mb << 20 : 0;
   }
-  if (max_coef && max_coef < group_bytes) max_coef = max_rgb = group_bytes;
+  if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
+  if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
   int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads) : JB_OK;
   if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
   // pass 2: entropy decoding on the host threads, all submitting to the shared context
@@ -521,6 +516,133 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
   }
   if (tot.first_error != JB_OK) return jb_fail_(nullptr, tot.first_error, tot.first_error_text.c_str());
   return JB_OK;
+}
+
+}  // namespace
+
+extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
+                                       size_t max_rgb_bytes, jb_batch_decoder **out) {
+  if (!out) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create: out is NULL");
+  *out = nullptr;
+  return create_single(device_id, clamp_threads(n_threads), max_coef_bytes, max_rgb_bytes, out);
+}
+
+extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_devices, int n_threads,
+                                             size_t max_coef_bytes, size_t max_rgb_bytes, jb_batch_decoder **out) {
+  if (!out || !device_ids) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create_multi: NULL pointer");
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 64) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_create_multi: 1..64 devices");
+  n_threads = clamp_threads(n_threads);
+  if (n_threads < n_devices) n_threads = n_devices;  // every device needs a host thread to feed it
+  jb_batch_decoder *top = new jb_batch_decoder();
+  top->device = device_ids[0];
+  for (int k = 0; k < n_devices; k++) {
+    // host threads are dealt out evenly; the first (n_threads % n_devices) devices get one more
+    const int share = n_threads / n_devices + (k < n_threads % n_devices ? 1 : 0);
+    jb_batch_decoder *part = nullptr;
+    int rc = create_single(device_ids[k], share, max_coef_bytes, max_rgb_bytes, &part);
+    if (rc != JB_OK) {
+      std::string text = jb_last_error(nullptr);
+      jb_batch_decoder_destroy(top);
+      return jb_fail_(nullptr, rc, text.c_str());
+    }
+    part->arena = &top->own_arena;
+    top->parts.push_back(part);
+  }
+  *out = top;
+  return JB_OK;
+}
+
+extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
+  if (!d) return;
+  for (jb_batch_decoder *p : d->parts) jb_batch_decoder_destroy(p);
+  for (auto &l : d->lanes) l.release();
+  jb_ctx_destroy(d->ctx);
+  jb_pinned_free(d->own_arena.base);
+  delete d;
+}
+
+extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
+  if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_arena: decoder is NULL");
+  if (d->arena != &d->own_arena) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: set the arena on the multi-device decoder, not on one of its parts");
+  jb_pinned_free(d->own_arena.base);
+  d->own_arena.base = nullptr;
+  d->own_arena.bytes = 0;
+  d->own_arena.used = 0;
+  if (bytes) {
+    // pinned against the (first) device of the decoder; portable, so every device copies into it
+    d->own_arena.base = (uint8_t *)jb_pinned_alloc_on(d->device, bytes);
+    if (!d->own_arena.base) return jb_fail_(nullptr, JB_ERR_HIP, "jb_batch_decoder_set_arena: pinned allocation failed");
+    d->own_arena.bytes = bytes;
+    // no pixel staging while an arena takes the pixels
+    for (auto &l : d->lanes) l.drop_out();
+    for (jb_batch_decoder *p : d->parts)
+      for (auto &l : p->lanes) l.drop_out();
+  }
+  return JB_OK;
+}
+
+extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *paths, int n_paths,
+                                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
+                                    double *times) {
+  if (!d || !paths || !rgb || !widths || !heights || !statuses)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_run: NULL pointer");
+  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
+  if (d->parts.empty()) return run_single(d, paths, n_paths, rgb, widths, heights, statuses, times, d->arena == &d->own_arena);
+  // multi-device: file i -> part i % n_parts (images are independent: nothing crosses devices);
+  // every part runs its share on its own host threads, concurrently with the others
+  const int np = (int)d->parts.size();
+  d->own_arena.used = 0;
+  const double t0 = now_s();
+  struct Share {
+    std::vector<const char *> paths;
+    std::vector<uint8_t *> rgb;
+    std::vector<int32_t> w, h;
+    std::vector<int> st;
+    double times[4] = {0, 0, 0, 0};
+    int rc = JB_OK;
+    std::string text;
+  };
+  std::vector<Share> sh((size_t)np);
+  for (int i = 0; i < n_paths; i++) sh[(size_t)(i % np)].paths.push_back(paths[i]);
+  std::vector<std::thread> th;
+  for (int k = 0; k < np; k++) {
+    Share &s = sh[(size_t)k];
+    const size_t n = s.paths.size();
+    s.rgb.assign(n, nullptr);
+    s.w.assign(n, 0);
+    s.h.assign(n, 0);
+    s.st.assign(n, JB_OK);
+    th.emplace_back([&, k] {
+      Share &m = sh[(size_t)k];
+      m.rc = run_single(d->parts[(size_t)k], m.paths.data(), (int)m.paths.size(), m.rgb.data(), m.w.data(), m.h.data(),
+                        m.st.data(), m.times, false);
+      if (m.rc != JB_OK) m.text = jb_last_error(nullptr);  // thread-local text: fetch it on this thread
+    });
+  }
+  for (auto &x : th) x.join();
+  int rc = JB_OK;
+  std::string text;
+  for (int i = 0; i < n_paths; i++) {
+    Share &s = sh[(size_t)(i % np)];
+    const size_t j = (size_t)(i / np);
+    rgb[i] = s.rgb[j];
+    widths[i] = s.w[j];
+    heights[i] = s.h[j];
+    statuses[i] = s.st[j];
+  }
+  for (int k = 0; k < np; k++)
+    if (rc == JB_OK && sh[(size_t)k].rc != JB_OK) {
+      rc = sh[(size_t)k].rc;
+      text = sh[(size_t)k].text;
+    }
+  if (times) {
+    times[0] = now_s() - t0;
+    times[1] = times[2] = times[3] = 0;
+    for (int k = 0; k < np; k++)
+      for (int j = 1; j < 4; j++) times[j] += sh[(size_t)k].times[j];
+  }
+  return rc == JB_OK ? JB_OK : jb_fail_(nullptr, rc, text.c_str());
 }
 
 extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,

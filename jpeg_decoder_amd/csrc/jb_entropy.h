@@ -68,7 +68,7 @@ struct HuffTable {
       for (int i = 0; i < counts[len]; i++, k++, code++) {
         const int rs = symbols[k], run = rs >> 4, mag = rs & 15;
         if (len + mag > kWideBits) continue;
-        if (mag == 0 && rs != 0 && rs != 0xf0) continue;  // undefined symbols: general path rejects
+        if (mag == 0 && rs != 0 && rs != 0xf0) continue;  // run-only symbols 0x10..0xE0: left to the general path, which (like reference jpeg.cpp:377-385) skips the run and stores nothing
         const int spare = kWideBits - len - mag;
         for (int m = 0; m < (1 << mag); m++) {
           int value = m;

@@ -33,6 +33,7 @@
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
+void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d);
 // general front end (jb_frontend_ext.cpp): progressive, grayscale, multi-scan files
 int jb_ext_decode_(const uint8_t *jpeg, size_t n, jb_image_desc *desc, uint16_t *qtabs, int16_t *coef,
                    size_t coef_cap_bytes, std::string *err);
@@ -235,7 +236,9 @@ int decode_scan_mt(const Frame &fr, const jb_geometry &g, int16_t *coef, int n_t
       break;  // EOI or any other marker ends the scan
     }
   }
-  stop.push_back(p < end ? p : end);
+  // the last interval ends at the marker the loop stopped on (EOI); a buffer that simply ends
+  // (no EOI) ends the interval at its last byte, as the serial decoder sees it
+  stop.push_back((p + 1 < end && p[0] == 0xff) ? p : end);
   if ((int64_t)start.size() != n_int) return decode_scan(fr, g, coef, e);
   if (n_threads > n_int) n_threads = (int)n_int;
   std::vector<int> rcs((size_t)n_threads, JB_OK);
@@ -306,7 +309,10 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   jb_geometry g;
   rc = jb_geometry_of(&desc, &g);
   if (rc) return jb_fail_(ctx, rc, "bad frame geometry");
-  int16_t *coef = (int16_t *)jb_pinned_alloc((size_t)g.coef_bytes);
+  // the staging ring follows the frame (a context sized for another image, or created with (0,0))
+  rc = jb_ctx_reserve(ctx, (size_t)g.coef_bytes, (size_t)g.rgb_bytes);
+  if (rc) return rc;
+  int16_t *coef = (int16_t *)jb_pinned_alloc_on(jb_ctx_device(ctx), (size_t)g.coef_bytes);
   if (!coef) return jb_fail_(ctx, JB_ERR_HIP, jb_last_error(nullptr));
   rc = jb_entropy_decode(jpeg, jpeg_bytes, &desc, qtabs, coef, (size_t)g.coef_bytes);
   uint8_t *out = nullptr;
@@ -324,6 +330,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   *rgb = out;
   *width = desc.width;
   *height = desc.height;
+  jb_ctx_set_last_desc_(ctx, &desc);
   return JB_OK;
 }
 

@@ -49,6 +49,14 @@ def main():
 
     f = counter("pmc_fetch", "FETCH_SIZE")
     w = counter("pmc_write", "WRITE_SIZE")
+    # L2 <-> fabric request mix (optional pass "pmc_req"): how many writes leave L2 as full 64-B
+    # requests; partial-line writes (odd row strides) show up as 32-B requests
+    for cname in ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"):
+        v = counter("pmc_req", cname)
+        if v:
+            summary[cname + "_avg"] = sum(v) / len(v)
+    if "TCC_EA0_WRREQ_sum_avg" in summary and summary["TCC_EA0_WRREQ_sum_avg"]:
+        summary["write_requests_64B_fraction"] = summary.get("TCC_EA0_WRREQ_64B_sum_avg", 0.0) / summary["TCC_EA0_WRREQ_sum_avg"]
     if f:
         summary["FETCH_SIZE_KiB_avg_raw"] = sum(f) / len(f)
     if w:
@@ -63,16 +71,24 @@ def main():
     # (JB_BENCH_ARGS in run_profile.sh) state theirs in JB_ALG_BYTES and do not become "latest"
     alg = int(os.environ.get("JB_ALG_BYTES", "4831838208"))
     summary["algorithmic_bytes_per_launch"] = alg
+    if "hbm_bytes_per_launch" in summary:
+        summary["traffic_ratio"] = summary["hbm_bytes_per_launch"] / alg
+    # the counters belong to ONE state of the kernel source: bench.py reports them as
+    # roofline.traffic only while jb_kernels.hip still has this content hash
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "..", "jpeg_decoder_amd", "csrc", "jb_kernels.hip"), "rb") as fh:
+        khash = hashlib.sha256(fh.read()).hexdigest()[:16]
+    summary["kernel_source_sha256_16"] = khash
     if "hbm_bytes_per_launch" in summary and alg == 4831838208:
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_latest.json"), "w") as fh:
-                json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": alg}, fh)
-            with open(os.path.join(out_dir, "pmc_latest.json"), "w") as fh:
-                json.dump({"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": alg}, fh)
-        except OSError:
-            pass
+        rec = {"tag": tag, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
+               "algorithmic_bytes_per_launch": alg, "kernel_source_sha256_16": khash}
+        for d in (here, out_dir):
+            try:
+                with open(os.path.join(d, "pmc_latest.json"), "w") as fh:
+                    json.dump(rec, fh)
+            except OSError:
+                pass
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_summary.json")
     # on the GPU box profiles/ is part of the scratch copy: also drop it under gpurun_out/
     with open(os.path.join(out_dir, f"{tag}_summary.json"), "w") as fh:

@@ -322,7 +322,7 @@ def test_front_end_fuzz_under_sanitizers(tmp_path):
         pytest.skip("no g++")
     d = os.path.join(ROOT, "tools", "fuzz")
     b = subprocess.run(["make", "-C", d], capture_output=True, text=True)
-    if b.returncode != 0 and "sanitize" in (b.stderr + b.stdout):
+    if b.returncode != 0 and ("cannot find -lasan" in b.stderr or "cannot find -lubsan" in b.stderr or "libasan" in b.stderr):
         pytest.skip("toolchain without sanitizer runtimes")
     assert b.returncode == 0, b.stderr[-2000:]
     seeds = sorted(os.path.join(GOLD, "images", f) for f in os.listdir(os.path.join(GOLD, "images")) if f.endswith(".jpg"))

@@ -80,3 +80,15 @@ def test_shard_edge_cases():
     assert all(len(shard_images(1024, r, 8)) == 128 for r in range(8))
     with pytest.raises(ValueError):
         shard_images(4, 4, 4)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """bench.py never prints n_gpus != --gpus: under a launcher whose WORLD_SIZE differs from --gpus
+    it exits 2 before touching the GPU (so this runs on the CPU)."""
+    import subprocess
+    for world, gpus in (("1", "8"), ("2", "1"), ("4", "2")):
+        env = dict(os.environ, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--steps", "1"],
+                           capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 2, (world, gpus, r.stdout, r.stderr)
+        assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,147 @@
+"""GPU parity of the BATCH form of decode(path) at BASELINE.json's batch configurations (-m gpu):
+jb_batch_decoder (single- and multi-device) over writer-made JPEG files, every decoded image
+compared bit-exactly with the oracle on the blocks that were written.
+  config 4: 1920x1080 4:4:4 files (>= 32), restart intervals on;
+  config 5: 8192x8192 4:2:0 files (>= 4), restart intervals on;
+  mixed:    one large 4:4:4 file next to many small 4:2:0 files (groups bounded by the pixel side).
+Each in malloc and arena output modes, >= 8 host threads, grouped and one-image-per-submission."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jb():
+    import jpeg_decoder_amd as jb
+    assert jb.lib().jb_device_count() >= 1, jb.lib().jb_last_error(None)
+    return jb
+
+
+def _write_files(tmp, tag, w, h, hs, vs, n_files, n_distinct, ri, oracle):
+    """n_files distinct images: n_distinct seeded synth images, the rest MCU-rotations of them.
+    -> (paths, expected RGB arrays)."""
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    bpm = hs * vs + 2
+    bases = [synth.synth_blocks(w, h, hs, vs, 300 + i) for i in range(n_distinct)]
+    paths, want = [], []
+    for i in range(n_files):
+        coef, q = bases[i % n_distinct]
+        if i >= n_distinct:
+            coef = np.roll(coef, (i * 131) * bpm, axis=0)
+        p = os.path.join(tmp, f"{tag}_{i}.jpg")
+        with open(p, "wb") as f:
+            f.write(synth.encode_jpeg(coef, w, h, hs, vs, q, restart_interval=ri))
+        paths.append(p)
+        want.append(oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=16))
+    return paths, want
+
+
+def _check(imgs, st, tm, want):
+    assert tm["rc"] == 0 and all(s == 0 for s in st), (tm, st)
+    for i, (g, w) in enumerate(zip(imgs, want)):
+        assert g is not None and g.shape == w.shape and np.array_equal(g, w), i
+
+
+@pytest.fixture(scope="module")
+def files_1080p(tmp_path_factory, oracle):
+    d = str(tmp_path_factory.mktemp("c4"))
+    return _write_files(d, "c4", 1920, 1080, 1, 1, 32, 4, 240, oracle)  # DRI = one MCU row
+
+
+@pytest.fixture(scope="module")
+def files_8192(tmp_path_factory, oracle):
+    d = str(tmp_path_factory.mktemp("c5"))
+    return _write_files(d, "c5", 8192, 8192, 2, 2, 4, 1, 512, oracle)  # DRI = one MCU row
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+@pytest.mark.parametrize("arena", [False, True])
+def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices):
+    """BASELINE config 4 (one GPU's share, as files): 32 x 1920x1080 4:4:4, 8 threads."""
+    paths, want = files_1080p
+    total = sum((w.size + 255) // 256 * 256 for w in want)
+    for group_mb in (None, "0"):
+        if group_mb is None:
+            monkeypatch.delenv("JPEGBLK_GROUP_MB", raising=False)
+        else:
+            monkeypatch.setenv("JPEGBLK_GROUP_MB", group_mb)
+        with jb.BatchDecoder(8, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
+            for _ in range(2):  # second run: buffers, ring and arena are reused
+                imgs, st, tm = dec.run(paths)
+                _check(imgs, st, tm, want)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+@pytest.mark.parametrize("arena", [False, True])
+def test_batch_decoder_config5_8192_420(jb, files_8192, arena, devices):
+    """BASELINE config 5 shape: 8192x8192 4:2:0 files (201 MB of coefficients and of pixels per
+    image), restart-interval splitting on (more host threads than files), 8 threads."""
+    paths, want = files_8192
+    total = sum((w.size + 255) // 256 * 256 for w in want)
+    with jb.BatchDecoder(8, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
+        imgs, st, tm = dec.run(paths)
+        _check(imgs, st, tm, want)
+    if not arena and devices is None:  # ring back-pressure: 2 threads, ring of 4 slots, 8 submissions
+        with jb.BatchDecoder(2, 0) as dec:
+            imgs, st, tm = dec.run(paths + paths)
+            _check(imgs, st, tm, want + want)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+@pytest.mark.parametrize("threads", [1, 8])
+@pytest.mark.parametrize("arena", [False, True])
+def test_batch_decoder_mixed_sizes_and_samplings(jb, oracle, tmp_path, arena, threads, devices):
+    """One 2048x1536 4:4:4 file (18.9 MB of coefficients, 9.4 MB of pixels) among 44 files of
+    679x451 4:2:0: the ring slots are sized by the large image, and a group of small 4:2:0 images
+    that fits its coefficient capacity (19 images) would overflow its pixel capacity (10) -- groups
+    are bounded by both."""
+    big_p, big_w = _write_files(str(tmp_path), "big", 2048, 1536, 1, 1, 1, 1, 0, oracle)
+    small_p, small_w = _write_files(str(tmp_path), "small", 679, 451, 2, 2, 44, 3, 0, oracle)
+    paths = small_p[:5] + big_p + small_p[5:]
+    want = small_w[:5] + big_w + small_w[5:]
+    total = sum((w.size + 255) // 256 * 256 for w in want)
+    with jb.BatchDecoder(threads, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
+        imgs, st, tm = dec.run(paths)
+        _check(imgs, st, tm, want)
+
+
+def test_multi_device_decoder_rejects_and_reports(jb, tmp_path):
+    """jb_batch_decoder_create_multi: a device that does not exist is reported at creation; a
+    failing file is reported per file at its original index, the rest decode."""
+    from conftest import BASELINE_IMAGES, GOLD, load_golden
+    with pytest.raises(jb.JbError) as e:
+        jb.BatchDecoder(4, devices=[0, 99])
+    assert e.value.status == -6
+    names = BASELINE_IMAGES + BASELINE_IMAGES[:3]
+    paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
+    paths.insert(3, str(tmp_path / "missing.jpg"))
+    with jb.BatchDecoder(4, devices=[0, 0, 0]) as dec:
+        imgs, st, tm = dec.run(paths)
+    assert tm["rc"] == -8 and st[3] == -8 and imgs[3] is None
+    k = 0
+    for i in range(len(paths)):
+        if i == 3:
+            continue
+        assert st[i] == 0 and np.array_equal(imgs[i], load_golden(names[k])[3]), i
+        k += 1
+
+
+def test_context_sizes_itself_from_the_frame(jb):
+    """A context created without staging (0,0) -- the Python and C++ default -- decodes files: the
+    ring is built from the parsed frame and grows with larger frames (jb_ctx_reserve)."""
+    from conftest import GOLD, load_golden
+    with jb.Context(0) as ctx:
+        assert ctx.device == 0
+        for name in ("img2", "img5", "img2"):  # small, larger (re-size), small again
+            got = ctx.decode_file(os.path.join(GOLD, "images", name + ".jpg"))
+            assert np.array_equal(got, load_golden(name)[3]), name
+    node = jb.lib().jb_device_numa_node(0)
+    assert node >= 0 or node == -7  # known, or reported as unknown (JB_ERR_STATE)
+    p = jb.lib().jb_pinned_alloc_on(0, 1 << 20)
+    assert p
+    jb.lib().jb_pinned_free(p)
+    assert not jb.lib().jb_pinned_alloc_on(99, 1 << 20)
