@@ -311,8 +311,8 @@ class BatchDecoder:
             _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))
             self._arena = True
 
-    def run(self, paths, keep_pixels=True):
-        return decode_batch(paths, keep_pixels=keep_pixels, _decoder=self._h, _arena=self._arena)
+    def run(self, paths, keep_pixels=True, on_image=None):
+        return decode_batch(paths, keep_pixels=keep_pixels, on_image=on_image, _decoder=self._h, _arena=self._arena)
 
     def close(self):
         if self._h:
@@ -326,8 +326,10 @@ class BatchDecoder:
         self.close()
 
 
-def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None, _arena=False):
-    """jb_decode_batch: -> (list of uint8 [H,W,3] arrays or None, statuses, times dict)."""
+def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, on_image=None, _decoder=None, _arena=False):
+    """jb_decode_batch: -> (list of uint8 [H,W,3] arrays or None, statuses, times dict).
+    on_image(i, view): called with a no-copy [H,W,3] view of every decoded image before its buffer
+    is released (checks over batches too large to keep)."""
     n = len(paths)
     arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
     rgb = (ctypes.c_void_p * n)()
@@ -342,8 +344,10 @@ def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, _decoder=None, 
     out = []
     for i in range(n):
         if rgb[i]:
+            m = w[i] * h[i] * 3
+            if on_image is not None:
+                on_image(i, np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).reshape(h[i], w[i], 3))
             if keep_pixels:
-                m = w[i] * h[i] * 3
                 a = np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).copy()
                 out.append(a.reshape(h[i], w[i], 3))
             else:

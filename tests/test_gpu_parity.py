@@ -538,7 +538,9 @@ def test_reference_with_the_integration_patch(tmp_path, name):
     root = os.path.dirname(os.path.dirname(GOLD))
     exe = os.path.join(root, "oracle", "_ref", "jpeg_patched")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/jpeg_patched not built (needs /root/reference at build time)")
+        # loud, not a silent skip: a run without the genuine-reference build has NOT proven the drop-in
+        pytest.xfail("oracle/_ref/jpeg_patched is absent (it is built from /root/reference by __graft_entry__.build(), "
+                     "is git-ignored and travels with gpurun): the integration patch was NOT exercised in this run")
     pytest.importorskip("PIL")
     from PIL import Image
     out = tmp_path / "o.ppm"

@@ -5,6 +5,10 @@
       optimisation -- the kind of file the reference's front end accepts);
   (2) PCIe-inclusive block pipeline: pre-decoded coefficient blocks in pinned host memory ->
       jb_submit/jb_wait ring -> pixels in pinned host memory (no Huffman).
+No rate is reported for unchecked pixels: before timing, every distinct file is decoded once through
+the single-image decode(path) (jb_decode_file -- the path tests/ pin bit-exact against the oracle),
+and EVERY image of the first timed pass of every configuration must equal that decode byte for byte
+(`pixels_checked` in the output).
 Every decode(path) line also carries the device-busy fraction (kernel time of the images decoded /
 wall time; the kernel time is measured on a resident copy of one image), i.e. how idle the GPU is
 while the host Huffman stage is the bottleneck.
@@ -120,6 +124,9 @@ def main():
         # warm-up (file cache, HIP init)
         jb.decode_batch(paths[:8], n_threads=4, device=device, keep_pixels=False)
         res = []
+        # what every image of a batch must decode to: the single-image decode(path) of its file
+        with jb.Context(device) as one:
+            want = {p: one.decode_file(p) for p in distinct}
         d0, q0, c0 = jb.entropy_decode(open(distinct[0], "rb").read())
         g0 = jb.geometry_of(d0)
         k_ms = kernel_ms_per_image(d0, q0, c0, device)
@@ -131,7 +138,16 @@ def main():
             arena = (n_mine * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
             with jb.BatchDecoder(t, device, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
                 dec.run(paths[:t], keep_pixels=False)          # touch every lane once
-                runs = [dec.run(paths, keep_pixels=False) for _ in range(args.repeat)]  # timed: contexts and pinned buffers exist
+                bad = []
+
+                def check(i, view):
+                    if not np.array_equal(view, want[paths[i]]):
+                        bad.append(i)
+
+                # timed: contexts and pinned buffers exist; the first pass hands every image to `check`
+                # (after the decoder's clock has stopped)
+                runs = [dec.run(paths, keep_pixels=False, on_image=check if k == 0 else None) for k in range(args.repeat)]
+                assert not bad, f"{mode}/{t} threads: {len(bad)} of {n_mine} images differ from the single-image decode: {bad[:8]}"
                 _, st, tm = min(runs, key=lambda x: x[2]["wall_s"])
                 walls = [round(x[2]["wall_s"], 3) for x in runs]
             assert all(s == 0 for s in st), st[:8]
@@ -144,7 +160,8 @@ def main():
                         "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1),
                         "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
                         "wall_s": round(tm["wall_s"], 3), "walls": walls,
-                        "device_busy_fraction": round(n_mine * k_ms * 1e-3 / tm["wall_s"], 4), "n_gpus": world})
+                        "device_busy_fraction": round(n_mine * k_ms * 1e-3 / tm["wall_s"], 4), "n_gpus": world,
+                        "pixels_checked": n_mine})
         out["decode_path"] = res
         if world > 1:
             if rank == 0:
