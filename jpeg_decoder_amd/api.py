@@ -356,7 +356,8 @@ def decode_batch(paths, n_threads=8, device=0, keep_pixels=True, on_image=None, 
                 lib().jb_free(rgb[i])
         else:
             out.append(None)
-    t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc}
+    t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc,
+         "error": lib().jb_last_error(None).decode(errors="replace") if rc else ""}
     return out, list(st), t
 
 

@@ -331,6 +331,7 @@ int jb_device_numa_node(int device_id) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, JB_ERR_HIP, "device %d not available (%d HIP devices visible)", device_id, ndev);
   int node = -1;
   if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device_id) == hipSuccess && node >= 0) return node;
+  (void)hipGetLastError();  // a runtime without that attribute: not an error of the caller's next HIP call
   // fallback: the PCI function's numa_node in sysfs
   char bdf[32] = {0};
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device_id) == hipSuccess) {

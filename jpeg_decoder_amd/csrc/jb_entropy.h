@@ -32,11 +32,62 @@ struct HuffTable {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
   uint16_t fast[512];
-  // AC tables only: kWideBits-bit lookahead that resolves the run/size code AND its magnitude bits
-  // in one step when both fit: (value << 16) | (control << 8) | bits consumed; control = run
-  // (0..16) | 0x40 for EOB | 0x80 for "no value" (ZRL); 0 = take the general path
+  // AC tables: kWideBits-bit lookahead that resolves up to TWO run/size symbols together with their
+  // magnitude bits in one step (T.81 F.2.2.1 EXTEND folded in).  The entropy stage is one serial
+  // dependency chain per scan -- bit buffer -> index -> table load -> shift -> bit buffer -- so what
+  // shortens it is fewer lookups per coefficient: at the usual qualities two short symbols fit the
+  // window often.  A symbol is (run, value, inc): k += run; out[zigzag[k]] = value; k += inc -- a
+  // ZRL is (16, 0, 0) and an absent second symbol (0, 0, 0), both of which store a zero at a
+  // position that is still zero, so the second symbol needs no branch of its own.
+  //   bits  0..3  bits consumed by both symbols (0 = take the general path)
+  //   bits  4..7  bits consumed by the first symbol alone (used when it completes the block)
+  //   bits  8..12 run1      13..17 run2      18 inc1   19 inc2   20 first is EOB   21 second is EOB
+  //   bits 32..47 value1    48..63 value2
   static constexpr int kWideBits = JB_WIDE_BITS;
-  int32_t wide[1 << kWideBits];
+  static_assert(kWideBits <= 15, "bit counts are stored in 4 bits");
+  uint64_t pair[1 << kWideBits];
+  // DC tables: code + difference bits in one lookup: (difference << 8) | bits consumed, 0 = general path
+  static constexpr int kDcBits = 10;
+  int32_t dcw[1 << kDcBits];
+
+  static constexpr uint64_t kInc1 = 1ull << 18, kInc2 = 1ull << 19, kEob1 = 1ull << 20, kEob2 = 1ull << 21;
+
+  // code length and symbol of the code that starts a `width`-bit window `w`; 0 = longer than the window
+  int window_symbol(uint32_t w, int width, int *sym) const {
+    int32_t code = 0;
+    for (int len = 1; len <= 16 && len <= width; len++) {
+      code = (int32_t)(w >> (width - len));
+      if (counts[len] && code <= maxcode[len] && code >= mincode[len]) {
+        *sym = symbols[valptr[len] + code - mincode[len]];
+        return len;
+      }
+    }
+    return 0;
+  }
+  // one AC symbol with its magnitude bits out of a `width`-bit window; returns bits used (0 = does
+  // not fit / not resolvable here) and the (run, value, inc, eob) it stands for
+  int window_ac(uint32_t w, int width, int *run, int *value, int *inc, bool *eob) const {
+    int rs = 0;
+    const int len = window_symbol(w, width, &rs);
+    if (!len) return 0;
+    const int r = rs >> 4, mag = rs & 15;
+    if (len + mag > width || mag > 10) return 0;
+    *eob = false;
+    if (rs == 0) {
+      *eob = true, *run = 0, *value = 0, *inc = 0;
+      return len;
+    }
+    if (rs == 0xf0) {
+      *run = 16, *value = 0, *inc = 0;
+      return len;
+    }
+    // run-only symbols 0x10..0xE0: left to the general path, which (like reference jpeg.cpp:377-385) skips the run and stores nothing
+    if (mag == 0) return 0;
+    const int m = (int)((w >> (width - len - mag)) & ((1u << mag) - 1));
+    *value = m < (1 << (mag - 1)) ? m - (1 << mag) + 1 : m;
+    *run = r, *inc = 1;
+    return len + mag;
+  }
 
   bool build(bool is_ac) {
     int code = 0, k = 0;
@@ -60,28 +111,37 @@ struct HuffTable {
       }
       code <<= 1;
     }
-    // combined code + magnitude lookup (T.81 F.2.2.1 EXTEND folded in); AC tables only
-    memset(wide, 0, sizeof wide);
-    code = 0;
-    k = 0;
-    for (int len = 1; is_ac && len <= 16; len++) {
-      for (int i = 0; i < counts[len]; i++, k++, code++) {
-        const int rs = symbols[k], run = rs >> 4, mag = rs & 15;
-        if (len + mag > kWideBits) continue;
-        if (mag == 0 && rs != 0 && rs != 0xf0) continue;  // run-only symbols 0x10..0xE0: left to the general path, which (like reference jpeg.cpp:377-385) skips the run and stores nothing
-        const int spare = kWideBits - len - mag;
-        for (int m = 0; m < (1 << mag); m++) {
-          int value = m;
-          if (mag && m < (1 << (mag - 1))) value = m - (1 << mag) + 1;
-          int ctl = run;
-          if (rs == 0) ctl = 0x40;
-          else if (rs == 0xf0) ctl = 16 | 0x80;
-          const int32_t e = (int32_t)((uint32_t)(value & 0xffff) << 16) | (ctl << 8) | (len + mag);
-          const int first = ((code << mag) | m) << spare;
-          for (int j = 0; j < (1 << spare); j++) wide[first + j] = e;
+    memset(pair, 0, sizeof pair);
+    memset(dcw, 0, sizeof dcw);
+    if (is_ac) {
+      for (uint32_t w = 0; w < (1u << kWideBits); w++) {
+        int run1, v1, inc1, run2 = 0, v2 = 0, inc2 = 0;
+        bool eob1, eob2 = false;
+        const int n1 = window_ac(w, kWideBits, &run1, &v1, &inc1, &eob1);
+        if (!n1) continue;
+        int n = n1;
+        if (!eob1 && n1 < kWideBits) {
+          const int rest = kWideBits - n1;
+          const int n2 = window_ac(w & ((1u << rest) - 1), rest, &run2, &v2, &inc2, &eob2);
+          if (n2) n += n2;
+          else run2 = v2 = inc2 = 0, eob2 = false;
         }
+        pair[w] = (uint64_t)n | ((uint64_t)n1 << 4) | ((uint64_t)run1 << 8) | ((uint64_t)run2 << 13) |
+                  (inc1 ? kInc1 : 0) | (inc2 ? kInc2 : 0) | (eob1 ? kEob1 : 0) | (eob2 ? kEob2 : 0) |
+                  ((uint64_t)(uint16_t)(int16_t)v1 << 32) | ((uint64_t)(uint16_t)(int16_t)v2 << 48);
       }
-      code <<= 1;
+    } else {
+      for (uint32_t w = 0; w < (1u << kDcBits); w++) {
+        int s = 0;
+        const int len = window_symbol(w, kDcBits, &s);
+        if (!len || s > 11 || len + s > kDcBits) continue;
+        int diff = 0;
+        if (s) {
+          const int m = (int)((w >> (kDcBits - len - s)) & ((1u << s) - 1));
+          diff = m < (1 << (s - 1)) ? m - (1 << s) + 1 : m;
+        }
+        dcw[w] = (int32_t)((uint32_t)diff << 8) | (len + s);
+      }
     }
     set = true;
     return true;
@@ -213,35 +273,55 @@ inline int extend(uint32_t v, int n) {
 // one block, reference decodeMCUComponent (jpeg.cpp:322-403)
 inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac, int &pred, int16_t *out) {
   memset(out, 0, 128);
-  const int s = decode_symbol(br, dc);
-  if (s < 0 || s > 11) return false;
-  const int diff = s ? extend(br.get(s), s) : 0;  // decode_symbol left >= 16 bits buffered
+  if (br.nbits < 32) br.refill();
+  int diff;
+  if (const int32_t fd = dc.dcw[br.peek(HuffTable::kDcBits)]) {  // code and difference bits in one lookup
+    br.drop(fd & 0xff);
+    diff = fd >> 8;
+  } else {
+    const int s = decode_symbol(br, dc);
+    if (s < 0 || s > 11) return false;
+    diff = s ? extend(br.get(s), s) : 0;  // decode_symbol left >= 16 bits buffered
+  }
   pred += diff;
   if (pred < -32768 || pred > 32767) return false;
   out[0] = (int16_t)pred;
   int k = 1;
   while (k < 64) {
     if (br.nbits < 32) br.refill();
-    const int32_t fa = ac.wide[br.peek(HuffTable::kWideBits)];
-    if (fa) {  // code and magnitude bits resolved by one lookup
-      const int ctl = (fa >> 8) & 0xff;
-      br.drop(fa & 0xff);
-      if (ctl & 0x40) break;  // EOB
-      k += ctl & 31;
+    const uint64_t e = ac.pair[br.peek(HuffTable::kWideBits)];
+    const int n = (int)(e & 15);
+    if (n) {  // up to two symbols, magnitude bits included, resolved by one lookup
+      if (e & HuffTable::kEob1) {
+        br.drop(n);
+        break;
+      }
+      k += (int)(e >> 8) & 31;
       if (k > 63) return false;  // reference jpeg.cpp:372-376
-      if (!(ctl & 0x80)) out[kZigZag[k++]] = (int16_t)(fa >> 16);
+      out[kZigZag[k]] = (int16_t)(e >> 32);
+      k += (int)(e >> 18) & 1;
+      if (k > 63) {  // the block is complete: what follows belongs to the next block
+        br.drop((int)(e >> 4) & 15);
+        break;
+      }
+      br.drop(n);
+      if (e & HuffTable::kEob2) break;
+      k += (int)(e >> 13) & 31;
+      if (k > 63) return false;
+      out[kZigZag[k]] = (int16_t)(e >> 48);  // (a zero onto a zero when there is no second symbol)
+      k += (int)(e >> 19) & 1;
       continue;
     }
     const int rs = decode_symbol(br, ac);
     if (rs < 0) return false;
     if (rs == 0) break;  // EOB
     int r = rs >> 4;
-    const int n = rs & 15;
+    const int nb = rs & 15;
     if (rs == 0xf0) r = 16;
-    if (k + r >= 64 || n > 10) return false;  // reference jpeg.cpp:372-385
+    if (k + r >= 64 || nb > 10) return false;  // reference jpeg.cpp:372-385
     k += r;
-    if (n) {
-      out[kZigZag[k]] = (int16_t)extend(br.get(n), n);  // <= 16 + 10 bits since the last refill
+    if (nb) {
+      out[kZigZag[k]] = (int16_t)extend(br.get(nb), nb);  // <= 16 + 10 bits since the last refill
       k++;
     }
   }

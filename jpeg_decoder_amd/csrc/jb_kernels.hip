@@ -207,6 +207,7 @@ __device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)
         "v"(g[3]), "v"(b[3]), "v"(b[2]), "v"(r[3]));  // %11 (w2 byte 2), %12 (w2 byte 3), %13, %14 -> w2 bytes 0,1
 }
 
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -285,6 +286,12 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
 #else
   constexpr bool kSplitRows = false;
 #endif
+  // The 4-pixel group that straddles the right image edge (width % 4 != 0): two stores from the packed
+  // words in the linear tiling -- the one small and odd-sized images take, where every row has such a
+  // group -- and the byte-store loop elsewhere: in the row-bound instantiations (4096 / 8192-pixel
+  // rows, where the case needs a width like 4093) and in 4:4:0 the extra code cost a wave per SIMD
+  // or spilled (hipcc's allocation of this kernel is at the edge: 94-96 of 96 VGPRs).
+  constexpr bool kTwoStoreTail = LINEAR && !(HS == 1 && VS == 2);
   constexpr bool kDirectLoad = !((NYT % 64 == 0) && (MCUS % 64 == 0) && (CB_OFF == 8192));  // all but 4:4:4
   __shared__ __attribute__((aligned(1024))) char lds[kStripBytes];
   const int tid = threadIdx.x;
@@ -568,14 +575,39 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
             uint8_t *const segp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x0 * 3;  // address of pixel px0
             const int rel = lane_late * 4 - px0;  // this lane's first pixel relative to the part
             if (p.fast_store && (part == 0 || rel >= 0)) {
-              // whole 4-pixel groups only (a group straddling the image edge is left to the tail
-              // below); the descriptor's range check drops the lanes past the part's end
+              // whole 4-pixel groups through one 12-byte store per lane; the descriptor's range
+              // check drops the lanes past the part's end
               pack12_rtz(r, g, b, w0, w1, w2);  // (again for the rare second part: cheaper than keeping it live)
+              const int voff = LINEAR ? rel * 3 : lane_late * 12;
               const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(segp, 0, (npx >> 2) * 12, 0x00020000);
-              __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, LINEAR ? rel * 3 : lane_late * 12, 0, JB_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, voff, 0, JB_STORE_AUX);
+              if (kTwoStoreTail && (npx & 3)) {
+                // the one group that straddles the right edge: its lane holds the 12 packed bytes and
+                // stores the 3, 6 or 9 inside the image with two stores (nine byte stores, each a
+                // wave-wide instruction, cost the odd-width bundled-image size 5 points of roofline)
+                // (the scalar offset carries the +2 / +4 / +8, and the lane test goes through an opaque
+                // copy: nothing of this rare path is hoisted into registers that live across the IDCT)
+                const __amdgpu_buffer_rsrc_t tail = __builtin_amdgcn_make_buffer_rsrc(segp, 0, 0x7ffffff0, 0x00020000);
+                int tv = voff;
+                asm volatile("" : "+v"(tv));
+                if (tv == (npx >> 2) * 12) {
+                  const int t = npx & 3;
+                  if (t == 3) {
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, tail, tv, 0, JB_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)w2, tail, tv, 8, JB_STORE_AUX);
+                  } else if (t == 2) {
+                    __builtin_amdgcn_raw_buffer_store_b32(w0, tail, tv, 0, JB_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)w1, tail, tv, 4, JB_STORE_AUX);
+                  } else {
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)w0, tail, tv, 0, JB_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w0 >> 16), tail, tv, 2, JB_STORE_AUX);
+                  }
+                }
+              }
             }
-            if (!p.fast_store || (npx & 3)) {
-              // the byte-store knob, or the one group that straddles the right edge: byte stores
+            if (!p.fast_store || (!kTwoStoreTail && (npx & 3))) {
+              // the byte-store knob (JPEGBLK_BYTE_STORE=1): every pixel through byte stores; and the
+              // straddling group of the instantiations without the two-store tail
               const int first = p.fast_store ? (npx & ~3) : 0;
               // opaque copy of a value that is live anyway: keeps this rare path's address
               // arithmetic from being hoisted out of the loop into registers
@@ -612,6 +644,9 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   // row-bound code is 2 % faster
   constexpr bool kCanLinear = ((LM::MCUS * 8 * HS / 4) % 64 == 0);
   const dim3 grid(p.n_tiles), block(LM::TB);
+  // hipGetLastError below must report THIS launch: an error left in the thread's error slot by an
+  // unrelated earlier call (a failed attribute query, say) is not this launch's
+  (void)hipGetLastError();
   // JPEGBLK_EXTRA_LDS (experiment): unused dynamic LDS per workgroup, to cap workgroups per CU
   static const unsigned extra_lds = getenv("JPEGBLK_EXTRA_LDS") ? (unsigned)atoi(getenv("JPEGBLK_EXTRA_LDS")) : 0u;
   if (kCanLinear && p.linear) {

@@ -41,7 +41,7 @@ def _write_files(tmp, tag, w, h, hs, vs, n_files, n_distinct, ri, oracle):
 
 
 def _check(imgs, st, tm, want):
-    assert tm["rc"] == 0 and all(s == 0 for s in st), (tm, st)
+    assert tm["rc"] == 0 and all(s == 0 for s in st), (tm["rc"], tm["error"], st)
     for i, (g, w) in enumerate(zip(imgs, want)):
         assert g is not None and g.shape == w.shape and np.array_equal(g, w), i
 
