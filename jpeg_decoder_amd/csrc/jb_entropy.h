@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/jpegblk.h"
 
@@ -326,6 +327,170 @@ inline bool decode_block(BitReader &br, const HuffTable &dc, const HuffTable &ac
     }
   }
   return true;
+}
+
+// ---- the fast path of the baseline front end: de-stuffed scan + branch-free refill ----------
+//
+// The entropy-coded segment is first copied into a clean buffer (FF00 -> FF, fill bytes dropped,
+// RSTn markers removed and their positions kept: memchr speed, ~1 % of the decode), so that the
+// bit reader can refill with one unaligned 8-byte load and no branch -- and restart intervals are
+// plain byte ranges, which is what lets several of them be decoded side by side.
+
+struct CleanScan {
+  // Worst case one block reads: 27 bits of DC + 63 x 26 bits of AC = 209 bytes; the readers check
+  // their position once per block, so this much zero padding behind the data keeps every load in bounds.
+  static constexpr size_t kPad = 512;
+  std::vector<uint8_t> bytes;  // clean data, then kPad zero bytes
+  std::vector<size_t> start;   // start[i] = first byte of restart interval i; the last entry = end of the data
+  int n_intervals() const { return (int)start.size() - 1; }
+};
+
+// [p, end): the entropy-coded bytes from the first byte after SOS to the end of the file buffer;
+// stops at EOI / any marker that is not RSTn (reference equivalent: readImageData, file.hpp:59-104)
+inline void unstuff(const uint8_t *p, const uint8_t *end, CleanScan &cs) {
+  cs.bytes.resize((size_t)(end - p) + CleanScan::kPad);
+  uint8_t *const base = cs.bytes.data();
+  uint8_t *o = base;
+  cs.start.clear();
+  cs.start.push_back(0);
+  while (p < end) {
+    const uint8_t *q = (const uint8_t *)memchr(p, 0xff, (size_t)(end - p));
+    if (!q) q = end;
+    memcpy(o, p, (size_t)(q - p));
+    o += q - p;
+    p = q;
+    if (p + 1 >= end) break;  // the end of the buffer, or a lone FF as its last byte
+    const uint8_t m = p[1];
+    if (m == 0x00) {
+      *o++ = 0xff;
+      p += 2;
+    } else if (m == 0xff) {
+      p += 1;  // fill byte (reference file.hpp:88-91)
+    } else if (m >= 0xd0 && m <= 0xd7) {
+      cs.start.push_back((size_t)(o - base));
+      p += 2;
+    } else {
+      break;  // EOI or any other marker ends the scan
+    }
+  }
+  cs.start.push_back((size_t)(o - base));
+  memset(o, 0, CleanScan::kPad);
+}
+
+// MSB-first reader over clean bytes.  refill() needs 8 readable bytes at p and leaves >= 56 valid
+// bits; it is unconditional and branch-free, so the caller places it by a static bit budget
+// instead of testing the fill level per symbol.
+struct CleanReader {
+  const uint8_t *p;
+  uint64_t acc = 0;
+  int nbits = 0;
+  explicit CleanReader(const uint8_t *b) : p(b) {}
+  inline void refill() {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    acc |= __builtin_bswap64(w) >> nbits;  // nbits <= 63 always
+    p += (63 - nbits) >> 3;
+    nbits |= 56;
+  }
+  inline uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
+  inline void drop(int n) {
+    acc <<= n;
+    nbits -= n;
+  }
+  inline uint32_t get(int n) {
+    if (n == 0) return 0;
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  // bits consumed since the reader was placed at `from`
+  inline int64_t consumed_bits(const uint8_t *from) const { return (int64_t)(p - from) * 8 - nbits; }
+};
+
+// canonical decode without a refill of its own: the caller guarantees >= 16 valid bits
+inline int decode_symbol_clean(CleanReader &br, const HuffTable &t) {
+  const uint16_t f = t.fast[br.peek(9)];
+  if (f) {
+    br.drop(f >> 8);
+    return f & 0xff;
+  }
+  int32_t code = (int32_t)br.peek(10);
+  int len = 10;
+  while (len <= 16 && code > t.maxcode[len]) {
+    len++;
+    code = (int32_t)br.peek(len);
+  }
+  if (len > 16) return -1;
+  br.drop(len);
+  return t.symbols[t.valptr[len] + code - t.mincode[len]];
+}
+
+// One block, reference decodeMCUComponent (jpeg.cpp:322-403); same results as decode_block above.
+// Bit budget: refill() leaves >= 56 bits; the DC lookup takes <= 10, each AC lookup <= kWideBits,
+// so four AC lookups follow one refill (the general path refills for itself).
+inline bool decode_block_clean(CleanReader &br, const HuffTable &dc, const HuffTable &ac, int &pred, int16_t *out) {
+  static_assert(HuffTable::kDcBits + 4 * HuffTable::kWideBits <= 56, "bit budget of the unrolled loop");
+  memset(out, 0, 128);
+  br.refill();
+  int diff;
+  if (const int32_t fd = dc.dcw[br.peek(HuffTable::kDcBits)]) {
+    br.drop(fd & 0xff);
+    diff = fd >> 8;
+  } else {
+    const int s = decode_symbol_clean(br, dc);
+    if (s < 0 || s > 11) return false;
+    diff = s ? extend(br.get(s), s) : 0;  // 16 + 11 bits of the 56
+    br.refill();
+  }
+  pred += diff;
+  if (pred < -32768 || pred > 32767) return false;
+  out[0] = (int16_t)pred;
+  int k = 1;
+  for (;;) {
+#pragma GCC unroll 4
+    for (int u = 0; u < 4; u++) {
+      const uint64_t e = ac.pair[br.peek(HuffTable::kWideBits)];
+      const int n = (int)(e & 15);
+      if (__builtin_expect(n != 0, 1)) {  // up to two symbols, magnitude bits included, in one lookup
+        if (e & HuffTable::kEob1) {
+          br.drop(n);
+          return true;
+        }
+        k += (int)(e >> 8) & 31;
+        if (k > 63) return false;  // reference jpeg.cpp:372-376
+        out[kZigZag[k]] = (int16_t)(e >> 32);
+        k += (int)(e >> 18) & 1;
+        if (k > 63) {  // the block is complete: what follows belongs to the next block
+          br.drop((int)(e >> 4) & 15);
+          return true;
+        }
+        br.drop(n);
+        if (e & HuffTable::kEob2) return true;
+        k += (int)(e >> 13) & 31;
+        if (k > 63) return false;
+        out[kZigZag[k]] = (int16_t)(e >> 48);  // (a zero onto a zero when there is no second symbol)
+        k += (int)(e >> 19) & 1;
+        if (k > 63) return true;
+      } else {
+        br.refill();
+        const int rs = decode_symbol_clean(br, ac);
+        if (rs < 0) return false;
+        if (rs == 0) return true;  // EOB
+        int r = rs >> 4;
+        const int nb = rs & 15;
+        if (rs == 0xf0) r = 16;
+        if (k + r >= 64 || nb > 10) return false;  // reference jpeg.cpp:372-385
+        k += r;
+        if (nb) {
+          out[kZigZag[k]] = (int16_t)extend(br.get(nb), nb);
+          k++;
+          if (k > 63) return true;
+        }
+        br.refill();
+      }
+    }
+    br.refill();
+  }
 }
 
 }  // namespace jbe

@@ -191,69 +191,62 @@ int decode_scan(const Frame &fr, const jb_geometry &g, int16_t *coef, Err &e) {
   return JB_OK;
 }
 
-// One restart interval on its own: MCUs [m0, m1) from the bytes [b, e) that lie between two RSTn
-// markers.  DC predictors start at 0 at every restart (T.81 F.2.1.3.1; reference jpeg.cpp:419-425),
-// so intervals are independent.
-int decode_interval(const Frame &fr, const jb_geometry &g, const uint8_t *b, const uint8_t *e_, int64_t m0,
-                    int64_t m1, int16_t *coef) {
-  BitReader br(b, e_);
+// One restart interval on its own: MCUs [m0, m1) from the clean bytes [b, b + len) that lay
+// between two RSTn markers.  DC predictors start at 0 at every restart (T.81 F.2.1.3.1; reference
+// jpeg.cpp:419-425), so intervals are independent.
+int decode_interval(const Frame &fr, const jb_geometry &g, const uint8_t *b, size_t len, const uint8_t *hard_limit,
+                    int64_t m0, int64_t m1, int16_t *coef) {
+  CleanReader br(b);
   int pred[3] = {0, 0, 0};
   const int ny = fr.desc.hs * fr.desc.vs;
   int16_t *out = coef + m0 * g.blocks_per_mcu * 64;
   for (int64_t m = m0; m < m1; m++)
     for (int blk = 0; blk < ny + 2; blk++) {
       const int c = blk < ny ? 0 : blk - ny + 1;
-      if (!decode_block(br, fr.dc[fr.dc_id[c]], fr.ac[fr.ac_id[c]], pred[c], out)) return JB_ERR_FORMAT;
+      if (!decode_block_clean(br, fr.dc[fr.dc_id[c]], fr.ac[fr.ac_id[c]], pred[c], out)) return JB_ERR_FORMAT;
+      if (br.p > hard_limit) return JB_ERR_FORMAT;  // ran off the end of the scan (the padding keeps the loads in bounds)
       out += 64;
     }
-  return br.overran() ? JB_ERR_FORMAT : JB_OK;
+  // more bits consumed than the interval holds: truncated or corrupt data
+  return br.consumed_bits(b) > (int64_t)len * 8 ? JB_ERR_FORMAT : JB_OK;
 }
 
-// Restart intervals decoded by n_threads host threads.  Falls back to the serial decoder (which
-// produces the precise error) whenever the markers found do not match the frame.
+// The scan: de-stuffed once (unstuff), then its restart intervals decoded by n_threads host
+// threads (1 = this thread).  When the RSTn markers found do not match the frame -- a marker
+// missing, an extra one, markers in a file without DRI -- the bit-serial reader above takes over:
+// it tolerates what the reference's reader tolerates and produces the precise error.
 int decode_scan_mt(const Frame &fr, const jb_geometry &g, int16_t *coef, int n_threads, Err &e) {
   const int64_t n_mcus = (int64_t)g.mcus_x * g.mcus_y;
   const int ri = fr.restart_interval;
-  if (n_threads <= 1 || ri <= 0 || n_mcus <= ri) return decode_scan(fr, g, coef, e);
-  const int64_t n_int = (n_mcus + ri - 1) / ri;
-  // split the entropy-coded segment at its RSTn markers (FF D0..D7; FF 00 is a stuffed byte)
-  std::vector<const uint8_t *> start, stop;
-  const uint8_t *p = fr.scan, *end = fr.scan + fr.scan_len;
-  start.push_back(p);
-  while (p + 1 < end) {
-    if (p[0] != 0xff) {
-      p++;
-      continue;
+  const int64_t n_int = ri > 0 ? (n_mcus + ri - 1) / ri : 1;
+  static thread_local CleanScan tls_scan;  // (kept per host thread: no allocation per image)
+  CleanScan &cs = tls_scan;  // a plain reference: the worker threads below must see THIS thread's buffer
+  unstuff(fr.scan, fr.scan + fr.scan_len, cs);
+  if ((int64_t)cs.n_intervals() != n_int) return decode_scan(fr, g, coef, e);
+  const uint8_t *base = cs.bytes.data();
+  const uint8_t *hard_limit = base + cs.start.back() + 8;
+  auto run = [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; i++) {
+      const int64_t m0 = ri > 0 ? i * ri : 0, m1 = (ri > 0 && m0 + ri < n_mcus) ? m0 + ri : n_mcus;
+      const int rc = decode_interval(fr, g, base + cs.start[(size_t)i], cs.start[(size_t)i + 1] - cs.start[(size_t)i],
+                                     hard_limit, m0, m1, coef);
+      if (rc != JB_OK) return rc;
     }
-    const uint8_t m = p[1];
-    if (m == 0x00 || m == 0xff) {
-      p += (m == 0x00) ? 2 : 1;
-    } else if (m >= 0xd0 && m <= 0xd7) {
-      stop.push_back(p);
-      p += 2;
-      start.push_back(p);
-    } else {
-      break;  // EOI or any other marker ends the scan
-    }
-  }
-  // the last interval ends at the marker the loop stopped on (EOI); a buffer that simply ends
-  // (no EOI) ends the interval at its last byte, as the serial decoder sees it
-  stop.push_back((p + 1 < end && p[0] == 0xff) ? p : end);
-  if ((int64_t)start.size() != n_int) return decode_scan(fr, g, coef, e);
+    return (int)JB_OK;
+  };
   if (n_threads > n_int) n_threads = (int)n_int;
+  if (n_threads <= 1) {
+    // a failure is re-examined by the bit-serial reader, which words the error ("restart marker
+    // missing", "ends early", ...) and is the authority on what is tolerated
+    return run(0, n_int) == JB_OK ? JB_OK : decode_scan(fr, g, coef, e);
+  }
   std::vector<int> rcs((size_t)n_threads, JB_OK);
   std::vector<std::thread> th;
   for (int t = 0; t < n_threads; t++)
-    th.emplace_back([&, t] {
-      const int64_t i0 = n_int * t / n_threads, i1 = n_int * (t + 1) / n_threads;
-      for (int64_t i = i0; i < i1 && rcs[(size_t)t] == JB_OK; i++) {
-        const int64_t m0 = i * ri, m1 = (m0 + ri < n_mcus) ? m0 + ri : n_mcus;
-        rcs[(size_t)t] = decode_interval(fr, g, start[(size_t)i], stop[(size_t)i], m0, m1, coef);
-      }
-    });
+    th.emplace_back([&, t] { rcs[(size_t)t] = run(n_int * t / n_threads, n_int * (t + 1) / n_threads); });
   for (auto &x : th) x.join();
   for (int rc : rcs)
-    if (rc != JB_OK) return set_err(e, rc, "corrupt entropy-coded data");
+    if (rc != JB_OK) return decode_scan(fr, g, coef, e);
   return JB_OK;
 }
 
