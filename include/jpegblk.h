@@ -205,6 +205,23 @@ int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *des
 int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                          uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes,
                          int n_threads);
+/* The entropy stage ON THE DEVICE (beyond the reference, whose decodeHuffman() -- jpeg.cpp:405-446 --
+ * is serial host code): for baseline files with restart intervals (DRI; e.g. the reference's
+ * images/img4.jpg) the host only parses the headers and removes the byte stuffing; every restart
+ * interval is then Huffman-decoded by its own GPU lane (the DC predictors reset at each restart,
+ * jpeg.cpp:419-425, so intervals are independent) with the host decoder's lookup tables, straight
+ * into the coefficient layout described above.  d_coef is a DEVICE pointer (16-byte aligned,
+ * capacity coef_cap_bytes); the result is integer-exact with jb_entropy_decode.  Synchronous.
+ * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (no DRI, markers that do not match
+ * the frame, more than two DC or AC tables, progressive ...) -- use jb_entropy_decode.
+ * JB_ERR_FORMAT: corrupt data.  jb_decode_file / jb_decode_memory / jb_batch_decoder take this path
+ * by themselves for files with 16 or more restart intervals (JPEGBLK_GPU_HUFFMAN=0 turns that
+ * off, =1 lowers the threshold to one interval) and fall back to the host decoder otherwise. */
+int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
+                             uint16_t *qtabs /* 4*64, may be NULL */, int16_t *d_coef, size_t coef_cap_bytes);
+/* How many images this context has decoded with the entropy stage on the device (through
+ * jb_decode_file / jb_decode_memory / a batch decoder): lets callers and tests see which path ran. */
+long long jb_ctx_device_entropy_images(const jb_ctx *ctx);
 /* decode(path) -> RGB: the reference's whole `Image(path); readJPEG();` surface
  * (jpeg.cpp:797-807, 826-907) minus the X11 sink.  *rgb is malloc'd (tight rows, width*3);
  * release it with jb_free(). */

@@ -104,6 +104,9 @@ def lib():
     L.jb_device_numa_node.argtypes = [ctypes.c_int]
     L.jb_ctx_reserve.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t]
     L.jb_ctx_device.argtypes = [vp]
+    L.jb_ctx_device_entropy_images.argtypes = [vp]
+    L.jb_ctx_device_entropy_images.restype = ctypes.c_longlong
+    L.jb_entropy_decode_device.argtypes = [vp, vp, ctypes.c_size_t, pd, vp, vp, ctypes.c_size_t]
     L.jb_pinned_free.argtypes = [vp]
     L.jb_pinned_free.restype = None
     L.jb_blocks_to_rgb_device.argtypes = [vp, ctypes.POINTER(DeviceBatch), vp]
@@ -207,6 +210,26 @@ class Context:
     @property
     def device(self):
         return lib().jb_ctx_device(self._h)
+
+    @property
+    def device_entropy_images(self):
+        """Images this context decoded with the entropy stage on the device."""
+        return lib().jb_ctx_device_entropy_images(self._h)
+
+    def entropy_decode_device(self, jpeg_bytes):
+        """jb_entropy_decode_device: JFIF bytes (with restart intervals) -> (desc, qtabs, coef int16
+        [n, 64]) with the Huffman stage on the GPU; the coefficients come back through a torch
+        tensor (plumbing).  Raises JbError(-9) when the stream is not eligible."""
+        import torch
+        buf = np.frombuffer(jpeg_bytes, dtype=np.uint8)
+        desc, q, _ = entropy_decode(jpeg_bytes, headers_only=True)
+        g = geometry_of(desc)
+        t = torch.full((g.n_coded_blocks, 64), 0x5a5a, dtype=torch.int16, device=f"cuda:{self.device}")
+        torch.cuda.synchronize()
+        d2 = ImageDesc()
+        q2 = np.zeros((4, 64), np.uint16)
+        _check(lib().jb_entropy_decode_device(self._h, _ptr(buf), buf.size, ctypes.byref(d2), _ptr(q2), t.data_ptr(), t.numel() * 2), self._h)
+        return d2, q2, t.cpu().numpy()
 
     def __enter__(self):
         return self

@@ -22,6 +22,7 @@
 
 #include "../../include/jpegblk.h"
 #include "jb_kernels.h"
+#include "jb_huff.h"
 
 namespace {
 
@@ -32,6 +33,14 @@ struct Slot {
   void *d_rgb = nullptr;
   int32_t *h_q = nullptr;  // pinned int32[3][64]
   int32_t *d_q = nullptr;
+  // device-side entropy decoding (jb_huff.hip): the submission's packed scans, interval tables and
+  // Huffman table sets (pinned host copy + device copy), and one status word per image
+  uint8_t *h_blob = nullptr;
+  void *d_blob = nullptr;
+  size_t blob_cap = 0;
+  uint32_t *h_status = nullptr;  // pinned, kMaxBatch words
+  uint32_t *d_status = nullptr;
+  int n_status = 0;              // images of the submission in flight whose status words must be checked
   hipEvent_t computed = nullptr;  // kernel finished (upload stream) -> the download may start
   hipEvent_t done = nullptr;      // pixels are in the caller's buffer
   bool busy = false;
@@ -49,8 +58,10 @@ struct jb_ctx {
   int n_slots = 0;
   int n_slots_req = 1;  // ring depth asked for at creation (used when jb_ctx_reserve builds the ring later)
   Slot slots[64];  // n_slots of them are in use
+  Slot huff_aux;   // blob + status of jb_entropy_decode_device (the only fields of it in use)
   int next_slot = 0;
   int next_ticket = 1;
+  long long n_device_entropy = 0;  // images whose entropy stage ran on the device (jb_huff.hip)
   jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
 };
@@ -180,8 +191,19 @@ void jb_ctx_destroy(jb_ctx *ctx) {
     if (s.d_rgb) (void)hipFree(s.d_rgb);
     if (s.d_q) (void)hipFree(s.d_q);
     if (s.h_q) (void)hipHostFree(s.h_q);
+    if (s.h_blob) (void)hipHostFree(s.h_blob);
+    if (s.d_blob) (void)hipFree(s.d_blob);
+    if (s.h_status) (void)hipHostFree(s.h_status);
+    if (s.d_status) (void)hipFree(s.d_status);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.computed) (void)hipEventDestroy(s.computed);
+  }
+  {
+    Slot &s = ctx->huff_aux;
+    if (s.h_blob) (void)hipHostFree(s.h_blob);
+    if (s.d_blob) (void)hipFree(s.d_blob);
+    if (s.h_status) (void)hipHostFree(s.h_status);
+    if (s.d_status) (void)hipFree(s.d_status);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -255,6 +277,8 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
 }
 
 int jb_ctx_device(const jb_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+long long jb_ctx_device_entropy_images(const jb_ctx *ctx) { return ctx ? ctx->n_device_entropy : 0; }
 
 int jb_ctx_last_desc(const jb_ctx *ctx, jb_image_desc *out) {
   if (!ctx || !out) return fail(nullptr, JB_ERR_NULL, "jb_ctx_last_desc: NULL pointer");
@@ -428,7 +452,209 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   return JB_OK;
 }
 
+// ---- device-side entropy decoding (jb_huff.hip) -------------------------------------------------
+// Pack the submission's images for the device decoder into the slot's pinned blob --
+//   [JbHuffImage x n][JbHuffWg x n_wg][JbHuffTables x n_sets][starts][scans, 16-byte aligned each]
+// -- upload it in one copy and launch the decoder: image i's coefficient blocks land at
+// d_out + i * coef_stride bytes, its status word at s.d_status[i].  Table sets are shared by the
+// images that use identical tables (the usual case: one set for the whole submission).
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int huff_stage(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int16_t *d_out, int64_t coef_stride, hipStream_t up) {
+  std::vector<int> set_of((size_t)n, 0);
+  std::vector<int> sets;  // index of the first job that owns each distinct table set
+  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
+  for (int i = 0; i < n; i++) {
+    int found = -1;
+    for (size_t k = 0; k < sets.size() && found < 0; k++)
+      if (memcmp(&jobs[sets[k]]->tables, &jobs[i]->tables, sizeof(JbHuffTables)) == 0) found = (int)k;
+    if (found < 0) {
+      found = (int)sets.size();
+      sets.push_back(i);
+    }
+    set_of[(size_t)i] = found;
+    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_starts += jobs[i]->starts.size();
+    scan_bytes += align16(jobs[i]->scan.size());
+  }
+  const size_t off_img = 0, off_wg = align16(off_img + (size_t)n * sizeof(JbHuffImage)),
+               off_tab = align16(off_wg + n_wg * sizeof(JbHuffWg)), off_starts = off_tab + sets.size() * sizeof(JbHuffTables),
+               off_scan = align16(off_starts + n_starts * 4), total = off_scan + scan_bytes;
+  if (total > 0xffffff00u || n_wg > 0x7fffffffu) return fail(ctx, JB_ERR_CAPACITY, "submission too large for the device entropy decoder");
+  if (total > s.blob_cap) {  // (the slot is idle: its previous submission has been waited for)
+    if (s.h_blob) (void)hipHostFree(s.h_blob);
+    if (s.d_blob) (void)hipFree(s.d_blob);
+    s.h_blob = nullptr, s.d_blob = nullptr, s.blob_cap = 0;
+    const size_t cap = total + total / 4 + 65536;
+    JB_HIP(ctx, hipHostMalloc((void **)&s.h_blob, cap, hipHostMallocDefault));
+    JB_HIP(ctx, hipMalloc(&s.d_blob, cap));
+    s.blob_cap = cap;
+  }
+  if (!s.h_status) {
+    JB_HIP(ctx, hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault));
+    JB_HIP(ctx, hipMalloc((void **)&s.d_status, 4 * 256));
+  }
+  uint8_t *const h = s.h_blob;
+  JbHuffImage *im = (JbHuffImage *)(h + off_img);
+  JbHuffWg *wg = (JbHuffWg *)(h + off_wg);
+  uint32_t *st = (uint32_t *)(h + off_starts);
+  size_t w = 0, si = 0, sc = off_scan;
+  for (size_t k = 0; k < sets.size(); k++) memcpy(h + off_tab + k * sizeof(JbHuffTables), &jobs[sets[k]]->tables, sizeof(JbHuffTables));
+  for (int i = 0; i < n; i++) {
+    const JbHuffJob &j = *jobs[i];
+    if ((int64_t)j.geo.coef_bytes > coef_stride && n > 1) return fail(ctx, JB_ERR_CAPACITY, "coefficient stride smaller than an image");
+    im[i] = j.img;
+    im[i].scan_off = (uint32_t)(sc - off_scan);
+    im[i].int_off = (uint32_t)si;
+    im[i].table_set = (uint32_t)set_of[(size_t)i];
+    im[i].coef_off = (int64_t)i * coef_stride;
+    for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
+    memcpy(st + si, j.starts.data(), j.starts.size() * 4);
+    si += j.starts.size();
+    memcpy(h + sc, j.scan.data(), j.scan.size());
+    sc += align16(j.scan.size());
+  }
+  JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, total, hipMemcpyHostToDevice, up));
+  JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)n, up));
+  JbHuffLaunch p;
+  const uint8_t *d = (const uint8_t *)s.d_blob;
+  p.scan = d + off_scan;
+  p.starts = (const uint32_t *)(d + off_starts);
+  p.tables = (const JbHuffTables *)(d + off_tab);
+  p.images = (const JbHuffImage *)(d + off_img);
+  p.wgs = (const JbHuffWg *)(d + off_wg);
+  p.coef = d_out;
+  p.status = s.d_status;
+  p.n_wgs = (int32_t)n_wg;
+  JB_HIP(ctx, jbk_huff_launch(p, up));
+  return JB_OK;
+}
+
+// One submission whose coefficients are produced ON the device: n images of one geometry, each a
+// prepared JbHuffJob.  Same ring, same ordering and same download as submit_impl; what is uploaded
+// is the compressed scan (a tenth of the coefficients), and the status words come back with the
+// pixels.  jb_wait / jb_poll report JB_ERR_FORMAT when the decoder met corrupt data.
+int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, uint8_t *rgb, int64_t rgb_stride, int *ticket) {
+  if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
+  if (n_images < 1 || n_images > kMaxBatch) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d outside 1..%d", n_images, kMaxBatch);
+  const jb_image_desc *desc = &jobs[0]->desc;
+  jb_geometry g;
+  int rc = check_desc(ctx, desc, &g);
+  if (rc) return rc;
+  const int64_t dev_stride = 3LL * desc->width;
+  if (rgb_stride < dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
+  const size_t coef_total = (size_t)g.coef_bytes * (size_t)n_images, rgb_total = (size_t)g.rgb_bytes * (size_t)n_images;
+  if (coef_total > ctx->max_coef || rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)
+    return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
+                desc->width, desc->height);
+  DeviceGuard guard(ctx->device);
+  Slot &s = ctx->slots[ctx->next_slot];
+  if (s.busy) {
+    JB_HIP(ctx, hipEventSynchronize(s.done));
+    s.busy = false;
+  }
+  hipStream_t up = ctx->stream, down = ctx->stream2 ? ctx->stream2 : ctx->stream;
+  if (n_images > 1) {
+    if (ctx->stream2 && (ctx->n_group_submits++ & 1u)) up = ctx->stream2;
+    down = up;
+  }
+  for (int i = 0; i < n_images; i++) {
+    rc = jb_resolve_qtabs(&jobs[i]->desc, jobs[i]->qtabs, s.h_q + (size_t)i * 192);
+    if (rc) return fail(ctx, rc, "bad quantisation table id");
+  }
+  JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768u * (size_t)n_images, hipMemcpyHostToDevice, up));
+  rc = huff_stage(ctx, s, jobs, n_images, (int16_t *)s.d_coef, g.coef_bytes, up);
+  if (rc) return rc;
+  jb_device_batch b;
+  memset(&b, 0, sizeof b);
+  b.desc = *desc;
+  b.n_images = n_images;
+  b.d_coef = (const int16_t *)s.d_coef;
+  b.coef_image_stride = g.coef_bytes;
+  b.d_qtabs = s.d_q;
+  b.qtab_image_stride = n_images > 1 ? 768 : 0;
+  b.d_rgb = (uint8_t *)s.d_rgb;
+  b.rgb_row_stride = dev_stride;
+  b.rgb_image_stride = g.rgb_bytes;
+  rc = jb_blocks_to_rgb_device(ctx, &b, up);
+  if (rc) return rc;
+  if (down != up) {
+    JB_HIP(ctx, hipEventRecord(s.computed, up));
+    JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+  }
+  if (rgb_stride == dev_stride)
+    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
+  else
+    JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                                 (size_t)desc->height, hipMemcpyDeviceToHost, down));
+  JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, down));
+  JB_HIP(ctx, hipEventRecord(s.done, down));
+  s.busy = true;
+  ctx->n_device_entropy += n_images;
+  s.n_status = n_images;
+  s.ticket = ctx->next_ticket++;
+  if (ctx->next_ticket < 0) ctx->next_ticket = 1;
+  *ticket = s.ticket;
+  ctx->next_slot = (ctx->next_slot + 1) % ctx->n_slots;
+  return JB_OK;
+}
+
+// after a submission has completed: did the device entropy decoder flag any of its images?
+int check_status(jb_ctx *ctx, Slot &s) {
+  const int n = s.n_status;
+  s.n_status = 0;
+  for (int i = 0; i < n; i++)
+    if (s.h_status[i])
+      return fail(ctx, JB_ERR_FORMAT, "device entropy decoder: corrupt entropy-coded data in image %d of the submission (status %u)", i, s.h_status[i]);
+  return JB_OK;
+}
+
 }  // namespace
+
+int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc, uint16_t *qtabs,
+                             int16_t *d_coef, size_t coef_cap_bytes) {
+  if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_entropy_decode_device: ctx is NULL");
+  if (!jpeg || !desc || !d_coef) return fail(ctx, JB_ERR_NULL, "jb_entropy_decode_device: NULL pointer");
+  JbHuffJob *job = new (std::nothrow) JbHuffJob();
+  if (!job) return fail(ctx, JB_ERR_CAPACITY, "out of host memory");
+  std::string err;
+  int rc = jb_huff_prepare_(jpeg, jpeg_bytes, job, &err);
+  if (rc == JB_OK && (size_t)job->geo.coef_bytes > coef_cap_bytes) rc = JB_ERR_CAPACITY, err = "coefficient buffer too small";
+  if (rc == JB_OK && ((uintptr_t)d_coef & 15)) rc = JB_ERR_GEOMETRY, err = "coefficient pointer must be a multiple of 16 bytes";
+  if (rc != JB_OK) {
+    delete job;
+    return fail(ctx, rc, "%s", err.c_str());
+  }
+  *desc = job->desc;
+  if (qtabs) memcpy(qtabs, job->qtabs, sizeof job->qtabs);
+  DeviceGuard guard(ctx->device);
+  Slot &s = ctx->huff_aux;
+  const JbHuffJob *jobs[1] = {job};
+  rc = huff_stage(ctx, s, jobs, 1, d_coef, job->geo.coef_bytes, ctx->stream);
+  delete job;  // (huff_stage copied everything into the pinned blob)
+  if (rc) return rc;
+  JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  s.n_status = 1;
+  return check_status(ctx, s);
+}
+
+// decode(bytes) with the entropy stage on the device: one prepared image through the ring
+// (used by jb_decode_memory, jb_frontend.cpp); the staging ring follows the frame
+int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_stride) {
+  int rc = jb_ctx_reserve(ctx, (size_t)job->geo.coef_bytes, (size_t)job->geo.rgb_bytes);
+  if (rc) return rc;
+  int ticket = -1;
+  const JbHuffJob *jobs[1] = {job};
+  rc = submit_jobs_impl(ctx, jobs, 1, rgb, rgb_stride, &ticket);
+  if (rc) return rc;
+  return jb_wait(ctx, ticket);
+}
+
+// several prepared images of ONE geometry in one submission (jb_batch.cpp); pixels contiguous, tight rows
+int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, int *ticket) {
+  return submit_jobs_impl(ctx, jobs, n, rgb, 3LL * jobs[0]->desc.width, ticket);
+}
 
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
               uint8_t *rgb, int64_t rgb_stride, int *ticket) {
@@ -454,7 +680,7 @@ int jb_wait(jb_ctx *ctx, int ticket) {
         JB_HIP(ctx, hipEventSynchronize(s.done));
         s.busy = false;
       }
-      return JB_OK;
+      return check_status(ctx, s);
     }
   }
   return fail(ctx, JB_ERR_STATE, "ticket %d is not in flight (already waited for and its slot reused?)", ticket);
@@ -471,7 +697,7 @@ int jb_poll(jb_ctx *ctx, int ticket) {
       if (e == hipErrorNotReady) return JB_PENDING;
       if (e != hipSuccess) return fail(ctx, JB_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(e));
       s.busy = false;
-      return JB_OK;
+      return check_status(ctx, s);
     }
   }
   return fail(ctx, JB_ERR_STATE, "ticket %d is not in flight (already waited for and its slot reused?)", ticket);

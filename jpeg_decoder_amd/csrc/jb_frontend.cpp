@@ -24,16 +24,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/jpegblk.h"
 #include "jb_entropy.h"
+#include "jb_huff.h"
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
 void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d);
+extern "C" int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_stride);  // jb_api.cpp
 // general front end (jb_frontend_ext.cpp): progressive, grayscale, multi-scan files
 int jb_ext_decode_(const uint8_t *jpeg, size_t n, jb_image_desc *desc, uint16_t *qtabs, int16_t *coef,
                    size_t coef_cap_bytes, std::string *err);
@@ -254,6 +257,76 @@ int report(jb_ctx *ctx, const Err &e) { return jb_fail_(ctx, e.code, e.msg.c_str
 
 }  // namespace
 
+// Ready one image for the device-side entropy decoder (jb_huff.hip): see jb_huff.h.
+int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err) {
+  Frame *fr = new Frame();
+  Err e;
+  int rc = parse_headers(jpeg, jpeg_bytes, *fr, e);
+  auto done = [&](int code, const char *msg) {
+    if (err) *err = msg ? msg : e.msg;
+    delete fr;
+    return code;
+  };
+  if (rc != JB_OK) return done(rc, nullptr);
+  job->desc = fr->desc;
+  memcpy(job->qtabs, fr->qtabs, sizeof job->qtabs);
+  rc = jb_geometry_of(&fr->desc, &job->geo);
+  if (rc != JB_OK) return done(rc, "bad frame geometry");
+  const int64_t n_mcus = (int64_t)job->geo.mcus_x * job->geo.mcus_y;
+  const int ri = fr->restart_interval;
+  if (ri <= 0) return done(JB_ERR_UNSUPPORTED, "no restart intervals: host decoder");
+  const int64_t n_int = (n_mcus + ri - 1) / ri;
+  // table slots: the three components may name at most two DC and two AC tables
+  int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
+  for (int c = 0; c < 3; c++) {
+    for (int kind = 0; kind < 2; kind++) {
+      int *ids = kind ? ac_ids : dc_ids;
+      const int id = kind ? fr->ac_id[c] : fr->dc_id[c];
+      int slot = ids[0] == id ? 0 : ids[1] == id ? 1 : -1;
+      if (slot < 0) {
+        slot = ids[0] < 0 ? 0 : ids[1] < 0 ? 1 : -1;
+        if (slot < 0) return done(JB_ERR_UNSUPPORTED, "more than two Huffman tables of one kind in use: host decoder");
+        ids[slot] = id;
+      }
+      (kind ? job->img.ac_slot : job->img.dc_slot)[c] = (uint8_t)slot;
+    }
+  }
+  job->img.dc_slot[3] = job->img.ac_slot[3] = 0;
+  memset(&job->tables, 0, sizeof job->tables);
+  for (int slot = 0; slot < 2; slot++) {
+    const HuffTable *t[2] = {dc_ids[slot] >= 0 ? &fr->dc[dc_ids[slot]] : nullptr, ac_ids[slot] >= 0 ? &fr->ac[ac_ids[slot]] : nullptr};
+    if (t[0]) memcpy(job->tables.dcw[slot], t[0]->dcw, sizeof t[0]->dcw);
+    if (t[1]) memcpy(job->tables.pair[slot], t[1]->pair, sizeof t[1]->pair);
+    for (int kind = 0; kind < 2; kind++) {
+      if (!t[kind]) continue;
+      const int at = 2 * kind + slot;
+      memcpy(job->tables.maxcode[at], t[kind]->maxcode, sizeof t[kind]->maxcode);
+      memcpy(job->tables.valptr[at], t[kind]->valptr, sizeof t[kind]->valptr);
+      memcpy(job->tables.mincode[at], t[kind]->mincode, sizeof t[kind]->mincode);
+      memcpy(job->tables.symbols[at], t[kind]->symbols, 256);
+    }
+  }
+  static_assert(sizeof(((HuffTable *)nullptr)->pair) == sizeof(((JbHuffTables *)nullptr)->pair[0]), "the device decoder uses the host decoder's AC lookup table");
+  static_assert(sizeof(((HuffTable *)nullptr)->dcw) == sizeof(((JbHuffTables *)nullptr)->dcw[0]), "and its DC lookup table");
+  static thread_local CleanScan tls_scan;
+  CleanScan &cs = tls_scan;
+  unstuff(fr->scan, fr->scan + fr->scan_len, cs);
+  if ((int64_t)cs.n_intervals() != n_int) return done(JB_ERR_UNSUPPORTED, "restart markers do not match the frame: host decoder");
+  if (cs.start.back() > 0xfffff000u) return done(JB_ERR_UNSUPPORTED, "scan too large for 32-bit offsets: host decoder");
+  job->scan_len = cs.start.back();
+  job->scan.assign(cs.bytes.begin(), cs.bytes.begin() + (long)(job->scan_len + 64));  // (unstuff zero-pads far beyond 64)
+  job->starts.resize(cs.start.size());
+  for (size_t i = 0; i < cs.start.size(); i++) job->starts[i] = (uint32_t)cs.start[i];
+  job->img.scan_off = job->img.int_off = job->img.table_set = 0;
+  job->img.scan_len = (uint32_t)job->scan_len;
+  job->img.n_int = (uint32_t)n_int;
+  job->img.ri = (uint32_t)ri;
+  job->img.n_mcus = (uint32_t)n_mcus;
+  job->img.ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
+  job->img.coef_off = 0;
+  return done(JB_OK, "");
+}
+
 extern "C" {
 
 int jb_entropy_decode(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc, uint16_t *qtabs,
@@ -295,6 +368,32 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   if (!ctx) return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_memory: ctx is NULL");
   if (!jpeg || !rgb || !width || !height) return jb_fail_(ctx, JB_ERR_NULL, "jb_decode_memory: NULL pointer");
   *rgb = nullptr;
+  // Files with restart intervals: the entropy stage runs on the device too (jb_huff.hip), the host
+  // only parses the headers and removes the byte stuffing.  JPEGBLK_GPU_HUFFMAN=0 keeps it on the
+  // host, =1 takes the device path for any number of intervals (default: 16 or more).  Whatever the
+  // device decoder does not take or flags as corrupt goes through the host decoder below, which
+  // gives the precise answer.
+  {
+    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
+    const uint32_t min_int = (knob && knob[0] == '1') ? 1u : 16u;
+    if (!(knob && knob[0] == '0')) {
+      std::unique_ptr<JbHuffJob> job(new JbHuffJob());
+      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && job->img.n_int >= min_int) {
+        uint8_t *out = (uint8_t *)malloc((size_t)job->geo.rgb_bytes);
+        if (!out) return jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
+        const int rc = jb_decode_job_(ctx, job.get(), out, 3LL * job->desc.width);
+        if (rc == JB_OK) {
+          *rgb = out;
+          *width = job->desc.width;
+          *height = job->desc.height;
+          jb_ctx_set_last_desc_(ctx, &job->desc);
+          return JB_OK;
+        }
+        free(out);
+        if (rc != JB_ERR_FORMAT) return rc;  // a HIP / capacity error is not the stream's fault
+      }
+    }
+  }
   jb_image_desc desc;
   uint16_t qtabs[256];
   int rc = jb_entropy_decode(jpeg, jpeg_bytes, &desc, qtabs, nullptr, 0);

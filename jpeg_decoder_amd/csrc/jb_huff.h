@@ -1,0 +1,77 @@
+// jb_huff.h -- internal interface of the device-side entropy decoder (jb_huff.hip): Huffman
+// decoding of a baseline scan on the GPU, one lane per restart interval.  Not part of the public
+// ABI.  Plain C structs shared by the host code that fills them (jb_frontend.cpp, jb_api.cpp) and
+// the kernel that reads them.
+#pragma once
+#include <stdint.h>
+
+// One table set: what the scans of one or more images decode with.  Slots 0/1 of each kind; an
+// image maps its three components onto them (JbHuffImage::dc_slot / ac_slot).  The lookup tables
+// are the host decoder's own (jbe::HuffTable::pair / dcw, jb_entropy.h) so that both decoders
+// resolve every code identically; the canonical arrays serve the general path (codes longer than
+// the lookup window).
+struct JbHuffTables {
+  uint64_t pair[2][2048];   // AC: up to two run/size symbols + magnitude bits per 11-bit window
+  int32_t dcw[2][1024];     // DC: code + difference bits per 10-bit window
+  int32_t maxcode[4][18];   // [0,1] = DC slots, [2,3] = AC slots
+  int32_t valptr[4][20];
+  int32_t mincode[4][20];
+  uint8_t symbols[4][256];
+};
+
+struct JbHuffImage {
+  uint32_t scan_off;   // byte offset of the image's clean scan in the scan buffer (multiple of 16)
+  uint32_t scan_len;   // clean bytes; at least 64 zero bytes follow
+  uint32_t int_off;    // index of the image's first entry in `starts` (n_int + 1 entries, bytes from scan_off)
+  uint32_t n_int;      // restart intervals
+  uint32_t ri;         // MCUs per interval
+  uint32_t n_mcus;     // MCUs in the image
+  uint32_t ny;         // luma blocks per MCU (blocks per MCU = ny + 2)
+  uint32_t table_set;  // index into the table sets
+  int64_t coef_off;    // byte offset of the image's coefficient blocks in the output
+  uint8_t dc_slot[4];  // table slot (0 / 1) of Y, Cb, Cr
+  uint8_t ac_slot[4];
+};
+
+struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart intervals of one image
+  uint32_t image;
+  uint32_t first_interval;
+};
+
+struct JbHuffLaunch {
+  const uint8_t *scan;         // device: clean entropy-coded bytes of all images
+  const uint32_t *starts;      // device: interval start offsets
+  const JbHuffTables *tables;  // device
+  const JbHuffImage *images;   // device
+  const JbHuffWg *wgs;         // device
+  int16_t *coef;               // device: output, decode-order int16 blocks (include/jpegblk.h)
+  uint32_t *status;            // device: one word per image, non-zero = corrupt data met (bit 0) / overrun (bit 1)
+  int32_t n_wgs;
+};
+
+constexpr int kJbHuffLanes = 128;  // restart intervals per workgroup (LDS: 42 KiB of tables + 128 B per lane < 64 KiB)
+// (the launch function is declared in jb_kernels.h: this header stays free of HIP types, the host
+// front end is also built for the CPU alone by tools/fuzz)
+
+// ---- host side (jb_frontend.cpp prepares, jb_api.cpp packs + launches) ----------------------
+#include <string>
+#include <vector>
+
+#include "../../include/jpegblk.h"
+
+// One image readied for the device decoder: headers parsed, scan de-stuffed, tables built.
+struct JbHuffJob {
+  jb_image_desc desc;
+  jb_geometry geo;
+  uint16_t qtabs[256];
+  JbHuffImage img;               // n_int, ri, n_mcus, ny, slots; offsets are filled by the packer
+  JbHuffTables tables;
+  std::vector<uint8_t> scan;     // clean bytes + >= 64 zero bytes
+  size_t scan_len = 0;           // clean bytes
+  std::vector<uint32_t> starts;  // n_int + 1 entries
+};
+// JB_OK: the image is eligible and `job` is filled.  JB_ERR_UNSUPPORTED: a valid stream the device
+// decoder does not take (no restart intervals, markers that do not match the frame, more than two
+// DC or AC tables in use, a frame for the general front end) -- use the host decoder.  Other
+// negatives: the header errors of jb_entropy_decode.
+int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err);

@@ -1,0 +1,254 @@
+// jb_huff.hip -- Huffman decoding of baseline scans ON THE DEVICE, one lane per restart interval
+// (gfx950).  Beyond the reference (its decodeHuffman, jpeg.cpp:405-446, is serial host code and
+// north_star keeps the entropy stage on the host): SURVEY.md section 8(f) rank 4.  Files with DRI
+// take this path; everything else stays on the host decoder (jb_frontend.cpp).
+//
+// Why it works: the DC predictors reset at every restart marker (T.81 F.2.1.3.1; reference
+// jpeg.cpp:419-425), so the intervals of a scan are independent bit streams -- after the host has
+// removed the byte stuffing and recorded where each interval starts (jbe::unstuff: memchr speed),
+// interval i is "decode ri MCUs from byte start[i]".  A lane does exactly what the host decoder
+// does for one interval, with the host decoder's own lookup tables (two AC symbols + magnitude
+// bits per 11-bit window, DC code + difference per 10-bit window), so the coefficients are
+// identical by construction; tests pin them against the reference's coefficient dumps
+// (images/img4.jpg has DRI = 100) and against the host decoder on writer- and libjpeg-made files.
+//
+// Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
+//   LDS: the image's table set (42 KiB: 2 AC pair tables, 2 DC tables, canonical arrays for the
+//   general path) + one 128-byte coefficient block per lane (16 KiB).
+//   The (MCU, block-in-MCU) loops are wave-uniform -- every interval holds the same number of MCUs
+//   but the image's last -- so the component, and with it the table, is uniform per iteration; only
+//   the symbol loop inside a block diverges.  A lane scatters its coefficients into its LDS block
+//   (de-zigzagged, ds_write_b16) and then writes the block out as 128 contiguous bytes: every HBM
+//   line is written whole by one lane, the layout is the fused pixel kernel's input.
+//   The bit stream is read through a 3-dword window per lane (two dwords in use, one prefetched);
+//   a lookup consumes at most 27 bits, so the window advances by at most one dword per step.
+// Safety: every stream read is clamped into the image's padded scan; k only grows inside a block
+// (at most 63 iterations); output indices come from host-validated counts.  Corrupt data sets the
+// image's status word and the host re-decodes that image with the serial reader for the precise
+// answer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jb_huff.h"
+#include "jb_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+struct Stream {
+  const uint8_t *base;  // the image's clean scan
+  uint32_t limit;       // highest byte offset a 4-byte read may start at (inside the zero padding)
+  uint32_t pos;         // byte offset of the next dword to fetch
+  uint32_t d0, d1, d2;  // window: bits come from d0:d1 at bit offset `off`; d2 is the prefetched next dword
+  uint32_t off;         // 0..31
+  __device__ __forceinline__ uint32_t fetch(uint32_t at) const {
+    return bswap32(*(const uint32_t *)(base + (at < limit ? at : limit)));
+  }
+  __device__ __forceinline__ void open(uint32_t start) {
+    pos = start & ~3u;
+    off = (start & 3u) * 8u;
+    d0 = fetch(pos);
+    d1 = fetch(pos + 4);
+    d2 = fetch(pos + 8);
+    pos += 12;
+  }
+  // the next 32 bits of the stream
+  __device__ __forceinline__ uint32_t window() const { return (uint32_t)(((((uint64_t)d0) << 32) | d1) << off >> 32); }
+  // n <= 32 - off_before + 1 is not required: any n <= 32 works, the window moves by one dword at most
+  __device__ __forceinline__ void consume(uint32_t n) {
+    off += n;
+    if (off >= 32) {
+      off -= 32;
+      d0 = d1;
+      d1 = d2;
+      d2 = fetch(pos);
+      pos += 4;
+    }
+  }
+  // bit position in the scan (from its first byte)
+  __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)(pos - 12) * 8 + off; }
+};
+
+__device__ __forceinline__ int extend(uint32_t v, int n) {  // T.81 F.2.2.1 EXTEND; reference jpeg.cpp:340-343
+  return (int)v < (1 << (n - 1)) ? (int)v - (1 << n) + 1 : (int)v;
+}
+
+struct LdsTables {
+  JbHuffTables t;
+};
+
+// canonical decode of one symbol (general path: codes longer than the lookup window); -1 = no such code
+__device__ __forceinline__ int canon_symbol(Stream &s, const JbHuffTables &t, int slot) {
+  const uint32_t bits = s.window();
+  int len = 1;
+  int32_t code = (int32_t)(bits >> 31);
+  while (len <= 16 && code > t.maxcode[slot][len]) {
+    len++;
+    code = (int32_t)(bits >> (32 - len));
+  }
+  if (len > 16) return -1;
+  s.consume((uint32_t)len);
+  return t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
+}
+
+__constant__ uint8_t kZigZagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                       12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                       58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+}  // namespace
+
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunch p) {
+  __shared__ __attribute__((aligned(16))) LdsTables lds;
+  __shared__ __attribute__((aligned(16))) uint8_t blocks[kJbHuffLanes * 128];
+  __shared__ uint8_t zz[64];
+  const int tid = threadIdx.x;
+  const JbHuffWg wg = p.wgs[blockIdx.x];
+  const JbHuffImage img = p.images[wg.image];
+
+  // the image's table set -> LDS (16-byte copies, the struct is a multiple of 16 bytes)
+  {
+    const uint4 *src = (const uint4 *)(p.tables + img.table_set);
+    uint4 *dst = (uint4 *)&lds.t;
+    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst[i] = src[i];
+    if (tid < 64) zz[tid] = kZigZagDev[tid];
+  }
+  __syncthreads();
+
+  const uint32_t iv = wg.first_interval + (uint32_t)tid;
+  const bool active = iv < img.n_int;
+  const uint32_t nb = img.ny + 2;
+  uint32_t count = 0, start = 0, end = 0;
+  if (active) {
+    const uint32_t m0 = iv * img.ri;
+    count = img.n_mcus - m0 < img.ri ? img.n_mcus - m0 : img.ri;
+    start = p.starts[img.int_off + iv];
+    end = p.starts[img.int_off + iv + 1];
+  }
+  Stream s;
+  s.base = p.scan + img.scan_off;
+  s.limit = ((img.scan_len + 3u) & ~3u) + 32u;  // inside the >= 64 zero bytes behind the data
+  s.open(start);
+
+  uint8_t *const blk_lds = blocks + tid * 128;
+  const uint32_t sw = ((uint32_t)tid & 7u) << 4;  // chunk swizzle: lane-strided 128-byte rows stay conflict-poor
+  int16_t *out = (int16_t *)((uint8_t *)p.coef + img.coef_off) + (int64_t)iv * img.ri * nb * 64;
+  int pred0 = 0, pred1 = 0, pred2 = 0;
+  uint32_t err = 0;
+
+  for (uint32_t mi = 0; mi < img.ri; mi++) {
+    if (__builtin_amdgcn_ballot_w64(mi < count) == 0) break;  // wave-uniform: no lane of this wave has MCUs left
+    for (uint32_t b = 0; b < nb; b++) {
+      const int c = b < img.ny ? 0 : (int)(b - img.ny) + 1;  // wave-uniform
+      const int dcs = img.dc_slot[c], acs = img.ac_slot[c];
+      if (mi < count) {
+        // ---- one block, as jbe::decode_block_clean does it (reference jpeg.cpp:322-403) ----
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(uint4 *)(blk_lds + (j << 4)) = uint4{0, 0, 0, 0};
+        int diff = 0;
+        {
+          const int32_t fd = lds.t.dcw[dcs][s.window() >> 22];
+          if (fd) {
+            s.consume((uint32_t)(fd & 0xff));
+            diff = fd >> 8;
+          } else {
+            const int sym = canon_symbol(s, lds.t, dcs);
+            if (sym < 0 || sym > 11) err |= 1;
+            else if (sym) {
+              const uint32_t v = s.window() >> (32 - sym);
+              s.consume((uint32_t)sym);
+              diff = extend(v, sym);
+            }
+          }
+        }
+        int pred = (c == 0 ? pred0 : c == 1 ? pred1 : pred2) + diff;
+        if (pred < -32768 || pred > 32767) err |= 1, pred = 0;
+        if (c == 0) pred0 = pred;
+        else if (c == 1) pred1 = pred;
+        else pred2 = pred;
+        *(int16_t *)(blk_lds + (0u ^ sw)) = (int16_t)pred;
+        int k = 1;
+        while (k < 64) {
+          const uint2 e = *(const uint2 *)&lds.t.pair[acs][s.window() >> 21];
+          const uint32_t lo = e.x, hi = e.y;
+          const uint32_t n = lo & 15u;
+          if (n) {  // up to two symbols, magnitude bits included, resolved by one lookup
+            if (lo & (1u << 20)) {  // EOB
+              s.consume(n);
+              break;
+            }
+            k += (int)((lo >> 8) & 31u);
+            if (k > 63) {
+              err |= 1;
+              break;
+            }
+            {
+              const uint32_t at = (uint32_t)zz[k] * 2u;
+              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)(hi & 0xffffu);
+            }
+            k += (int)((lo >> 18) & 1u);
+            if (k > 63) {  // the block is complete: what follows belongs to the next block
+              s.consume((lo >> 4) & 15u);
+              break;
+            }
+            s.consume(n);
+            if (lo & (1u << 21)) break;  // the second symbol is EOB
+            k += (int)((lo >> 13) & 31u);
+            if (k > 63) {
+              err |= 1;
+              break;
+            }
+            {
+              const uint32_t at = (uint32_t)zz[k] * 2u;
+              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)(hi >> 16);  // (a zero onto a zero when there is no second symbol)
+            }
+            k += (int)((lo >> 19) & 1u);
+          } else {  // general path: a code longer than the window, or a run-only symbol
+            const int rs = canon_symbol(s, lds.t, 2 + acs);
+            if (rs < 0) {
+              err |= 1;
+              break;
+            }
+            if (rs == 0) break;  // EOB
+            int r = rs >> 4;
+            const int nbits = rs & 15;
+            if (rs == 0xf0) r = 16;
+            if (k + r >= 64 || nbits > 10) {  // reference jpeg.cpp:372-385
+              err |= 1;
+              break;
+            }
+            k += r;
+            if (nbits) {
+              const uint32_t v = s.window() >> (32 - nbits);
+              s.consume((uint32_t)nbits);
+              const uint32_t at = (uint32_t)zz[k] * 2u;
+              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)extend(v, nbits);
+              k++;
+            }
+          }
+        }
+        // ---- the block leaves as 128 contiguous bytes: whole HBM lines, the pixel kernel's layout ----
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t v = *(const u32x4_t *)(blk_lds + (((uint32_t)j << 4) ^ sw));
+          __builtin_nontemporal_store(v, (u32x4_t *)out + j);
+        }
+        out += 64;
+      }
+    }
+  }
+  if (active) {
+    // more bits consumed than the interval holds: truncated or corrupt data
+    if (s.bitpos() > (uint64_t)end * 8) err |= 2;
+    if (err) atomicOr(p.status + wg.image, err);
+  }
+}
+
+hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
+  if (p.n_wgs <= 0) return hipSuccess;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(jb_huff_kernel, dim3((unsigned)p.n_wgs), dim3(kJbHuffLanes), 0, stream, p);
+  return hipGetLastError();
+}

@@ -31,3 +31,7 @@ int jbk_linear_ok(int hs, int vs, int mcus_x);
 // Launch the fused kernel for luma sampling (hs, vs): one 192-lane workgroup per tile.
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream);
 const char *jbk_kernel_name(int hs, int vs);
+
+// Device-side entropy decoder (jb_huff.hip); structures in jb_huff.h.
+struct JbHuffLaunch;
+hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream);

@@ -36,6 +36,8 @@ void *jb_pinned_alloc(size_t n) { return malloc(n); }
 void *jb_pinned_alloc_on(int, size_t n) { return malloc(n); }
 int jb_ctx_reserve(jb_ctx *, size_t, size_t) { return JB_OK; }
 int jb_ctx_device(const jb_ctx *) { return 0; }
+struct JbHuffJob;
+int jb_decode_job_(jb_ctx *, const JbHuffJob *, uint8_t *, int64_t) { return JB_OK; }
 void jb_pinned_free(void *p) { free(p); }
 void jb_free(void *p) { free(p); }
 int jb_blocks_to_rgb(jb_ctx *, const jb_image_desc *, const int16_t *, const uint16_t *, uint8_t *, int64_t) { return JB_OK; }
