@@ -266,6 +266,9 @@ void jb_batch_decoder_destroy(jb_batch_decoder *dec);
  * allocation shared by all devices. */
 int jb_batch_decoder_create_multi(const int *device_ids, int n_devices, int n_threads, size_t max_coef_bytes,
                                   size_t max_rgb_bytes, jb_batch_decoder **out);
+/* Images this decoder's current context(s) decoded with the entropy stage on the device (files with
+ * restart intervals, see jb_entropy_decode_device); the count restarts when a run re-sizes the ring. */
+long long jb_batch_decoder_device_entropy_images(const jb_batch_decoder *dec);
 /* Optional pinned output arena owned by the decoder (bytes = 0 releases it).  With an arena,
  * jb_batch_decoder_run places every decoded image in it -- rgb[i] points INTO the arena: do not
  * jb_free it; it stays valid until the next run, set_arena or destroy -- and the device writes the

@@ -123,6 +123,8 @@ def lib():
     L.jb_batch_decoder_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.jb_batch_decoder_create_multi.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                                 ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.jb_batch_decoder_device_entropy_images.argtypes = [vp]
+    L.jb_batch_decoder_device_entropy_images.restype = ctypes.c_longlong
     L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
@@ -333,6 +335,10 @@ class BatchDecoder:
         if arena_bytes:
             _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))
             self._arena = True
+
+    @property
+    def device_entropy_images(self):
+        return lib().jb_batch_decoder_device_entropy_images(self._h)
 
     def run(self, paths, keep_pixels=True, on_image=None):
         return decode_batch(paths, keep_pixels=keep_pixels, on_image=on_image, _decoder=self._h, _arena=self._arena)

@@ -534,7 +534,8 @@ int huff_stage(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int16_
 // prepared JbHuffJob.  Same ring, same ordering and same download as submit_impl; what is uploaded
 // is the compressed scan (a tenth of the coefficients), and the status words come back with the
 // pixels.  jb_wait / jb_poll report JB_ERR_FORMAT when the decoder met corrupt data.
-int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, uint8_t *rgb, int64_t rgb_stride, int *ticket) {
+int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, uint8_t *rgb, int64_t rgb_stride,
+                     uint32_t *status_out, int *ticket) {
   if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
   if (n_images < 1 || n_images > kMaxBatch) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d outside 1..%d", n_images, kMaxBatch);
   const jb_image_desc *desc = &jobs[0]->desc;
@@ -587,11 +588,14 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, ui
   else
     JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
                                  (size_t)desc->height, hipMemcpyDeviceToHost, down));
-  JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, down));
+  // the status words travel with the pixels: into the caller's (pinned) words when it keeps its own
+  // -- many threads share this ring, a slot's words may be recycled before their owner looks -- else
+  // into the slot's, which jb_wait / jb_poll check
+  JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, down));
   JB_HIP(ctx, hipEventRecord(s.done, down));
   s.busy = true;
   ctx->n_device_entropy += n_images;
-  s.n_status = n_images;
+  s.n_status = status_out ? 0 : n_images;
   s.ticket = ctx->next_ticket++;
   if (ctx->next_ticket < 0) ctx->next_ticket = 1;
   *ticket = s.ticket;
@@ -646,14 +650,14 @@ int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_
   if (rc) return rc;
   int ticket = -1;
   const JbHuffJob *jobs[1] = {job};
-  rc = submit_jobs_impl(ctx, jobs, 1, rgb, rgb_stride, &ticket);
+  rc = submit_jobs_impl(ctx, jobs, 1, rgb, rgb_stride, nullptr, &ticket);
   if (rc) return rc;
   return jb_wait(ctx, ticket);
 }
 
 // several prepared images of ONE geometry in one submission (jb_batch.cpp); pixels contiguous, tight rows
-int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, int *ticket) {
-  return submit_jobs_impl(ctx, jobs, n, rgb, 3LL * jobs[0]->desc.width, ticket);
+int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, uint32_t *status_out, int *ticket) {
+  return submit_jobs_impl(ctx, jobs, n, rgb, 3LL * jobs[0]->desc.width, status_out, ticket);
 }
 
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,

@@ -24,10 +24,16 @@
 #include <sched.h>
 #include <sys/mman.h>
 
+#include <memory>
+
 #include "../../include/jpegblk.h"
+#include "jb_huff.h"
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
+// device-side entropy decoding: several prepared images of one geometry in one submission; the
+// images' status words (0 = decoded cleanly) are copied to `status_out` (pinned) with the pixels
+extern "C" int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, uint32_t *status_out, int *ticket);
 // jb_wait in two halves, so that many threads can wait on one shared context (jb_api.cpp):
 // under the caller's lock, the event to block on (nullptr: the submission has completed) ...
 void *jb_wait_begin_(jb_ctx *ctx, int ticket);
@@ -118,6 +124,7 @@ constexpr int kSlots = 2;      // pinned buffers per host thread: decode image k
 struct Lane {
   int16_t *coef[kSlots] = {nullptr, nullptr};
   uint8_t *out[kSlots] = {nullptr, nullptr};
+  uint32_t *status[kSlots] = {nullptr, nullptr};  // per image of a group decoded on the device: its status word
   size_t cap_coef = 0, cap_rgb = 0;
   bool has_out = false;
 
@@ -132,6 +139,10 @@ struct Lane {
     for (int s = 0; s < kSlots && rc == JB_OK; s++) {
       coef[s] = (int16_t *)jb_pinned_alloc_on(device, need_coef);
       if (!coef[s]) rc = JB_ERR_HIP;
+      if (rc == JB_OK && !status[s]) {
+        status[s] = (uint32_t *)jb_pinned_alloc_on(device, 4 * 256);
+        if (!status[s]) rc = JB_ERR_HIP;
+      }
       if (with_out && rc == JB_OK) {
         out[s] = (uint8_t *)jb_pinned_alloc_on(device, need_rgb);
         if (!out[s]) rc = JB_ERR_HIP;
@@ -157,6 +168,8 @@ struct Lane {
     for (int s = 0; s < kSlots; s++) {
       jb_pinned_free(coef[s]);
       coef[s] = nullptr;
+      jb_pinned_free(status[s]);
+      status[s] = nullptr;
     }
     drop_out();
     cap_coef = cap_rgb = 0;
@@ -244,7 +257,14 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   double t_entropy = 0, t_wait = 0;
   struct Group {
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
+    bool on_device = false;              // the group's entropy stage ran on the device (jb_huff.hip)
   } grp[kSlots];
+  // Files with restart intervals: the entropy stage runs on the device, this thread only parses,
+  // removes the byte stuffing and packs (JPEGBLK_GPU_HUFFMAN: 0 = never, 1 = from one interval on;
+  // default: 16 intervals or more).  A group is all-device or all-host.
+  const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
+  const bool dev_entropy = !(knob && knob[0] == '0');
+  const uint32_t min_intervals = (knob && knob[0] == '1') ? 1u : 16u;
   std::vector<uint16_t> qtabs;
   auto index_of = [&](int k) { return t + k * r.n_threads; };
   auto report = [&](int i, int st, const std::string &text) {
@@ -272,9 +292,35 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     const size_t rgb_bytes = (size_t)parsed[(size_t)g.first].geo.rgb_bytes;
     for (int j = 0; j < g.n; j++) {
       const int i = index_of(g.first + j);
-      if (st == JB_OK && !use_arena)  // pinned staging -> the caller's (pageable) buffer
-        memcpy(r.rgb[i], lane->out[s] + (size_t)j * rgb_bytes, rgb_bytes);
-      report(i, st, text);
+      Parsed &p = parsed[(size_t)(g.first + j)];
+      int st_j = st;
+      std::string text_j = text;
+      uint8_t *const staged = use_arena ? r.rgb[i] : lane->out[s] + (size_t)j * rgb_bytes;
+      if (st == JB_OK && g.on_device && lane->status[s][j] != 0) {
+        // the device decoder met data it calls corrupt: the host decoder is the authority -- this one
+        // image again, entropy stage on the host (the slot's coefficient buffer is free: the group is done)
+        st_j = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, lane->coef[s], lane->cap_coef);
+        if (st_j == JB_OK) {
+          int ticket = -1;
+          void *ev2 = nullptr;
+          {
+            std::lock_guard<std::mutex> lk(r.dev->mu);
+            st_j = jb_submit_batch(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket);
+            if (st_j == JB_OK) ev2 = jb_wait_begin_(r.dev->ctx, ticket);
+            else text_j = jb_last_error(r.dev->ctx);
+          }
+          if (st_j == JB_OK && ev2) st_j = jb_wait_block_(r.dev->ctx, ev2);
+        } else {
+          text_j = jb_last_error(nullptr);
+        }
+      }
+      if (g.on_device) {
+        p.bytes.clear();
+        p.bytes.shrink_to_fit();
+      }
+      if (st_j == JB_OK && !use_arena)  // pinned staging -> the caller's (pageable) buffer
+        memcpy(r.rgb[i], staged, rgb_bytes);
+      report(i, st_j, text_j);
     }
     t_wait += now_s() - a;
     g.n = 0;
@@ -307,12 +353,30 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int room = (int)(room_c < room_p ? room_c : room_p);
     if (room > kMaxGroup) room = kMaxGroup;
     if (room < 1) room = 1;  // (cannot happen: the capacities cover the largest single image)
-    // entropy-decode consecutive images of the head's geometry into the slot, back to back
+    // entropy-decode consecutive images of the head's geometry into the slot, back to back -- or,
+    // for files with restart intervals, only ready them for the device decoder
     int n = 0;
+    bool on_device = false;
+    std::vector<std::unique_ptr<JbHuffJob>> jobs;
     while (n < room && k + n < n_mine) {
       Parsed &p = parsed[(size_t)(k + n)];
       if (n > 0 && (p.status != JB_OK || !same_geometry(head, p))) break;
       double a = now_s();
+      std::unique_ptr<JbHuffJob> job;
+      bool eligible = false;
+      if (dev_entropy) {
+        job.reset(new JbHuffJob());
+        eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr) == JB_OK && job->img.n_int >= min_intervals;
+      }
+      if (n == 0) on_device = eligible;
+      else if (eligible != on_device) break;  // the next group starts with this image
+      if (on_device) {
+        memcpy(p.qtabs, job->qtabs, sizeof p.qtabs);
+        jobs.push_back(std::move(job));
+        t_entropy += now_s() - a;
+        n++;  // (the file bytes stay until the group has come back clean)
+        continue;
+      }
       // fewer files than host threads: the spare threads split each image's restart intervals
       int st = jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs,
                                     lane->coef[s] + (size_t)n * (coef_bytes / 2), coef_bytes, r.inner_threads);
@@ -361,7 +425,13 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       // every copy of the submission is pinned <-> device, so this returns at once and the
       // transfers and the kernel run while this thread decodes its next group
       std::lock_guard<std::mutex> lk(r.dev->mu);
-      st = jb_submit_batch(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
+      if (on_device) {
+        std::vector<const JbHuffJob *> ptrs;
+        for (auto &j : jobs) ptrs.push_back(j.get());
+        st = jb_submit_jobs_(r.dev->ctx, ptrs.data(), n, dst, lane->status[s], &grp[s].ticket);
+      } else {
+        st = jb_submit_batch(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
+      }
       if (st != JB_OK) text = jb_last_error(r.dev->ctx);
       t_wait += now_s() - a;
     }
@@ -370,6 +440,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     } else {
       grp[s].first = k;
       grp[s].n = n;
+      grp[s].on_device = on_device;
       slot = (slot + 1) % kSlots;
     }
     k += n;
@@ -643,6 +714,13 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
       for (int j = 1; j < 4; j++) times[j] += sh[(size_t)k].times[j];
   }
   return rc == JB_OK ? JB_OK : jb_fail_(nullptr, rc, text.c_str());
+}
+
+extern "C" long long jb_batch_decoder_device_entropy_images(const jb_batch_decoder *d) {
+  if (!d) return 0;
+  long long n = d->ctx ? jb_ctx_device_entropy_images(d->ctx) : 0;
+  for (const jb_batch_decoder *p : d->parts) n += jb_batch_decoder_device_entropy_images(p);
+  return n;
 }
 
 extern "C" int jb_decode_batch(int device_id, const char *const *paths, int n_paths, int n_threads,

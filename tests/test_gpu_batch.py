@@ -58,12 +58,19 @@ def files_8192(tmp_path_factory, oracle):
     return _write_files(d, "c5", 8192, 8192, 2, 2, 4, 1, 512, oracle)  # DRI = one MCU row
 
 
+@pytest.mark.parametrize("entropy", ["host", "device"])
 @pytest.mark.parametrize("devices", [None, [0, 0]])
 @pytest.mark.parametrize("arena", [False, True])
-def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices):
-    """BASELINE config 4 (one GPU's share, as files): 32 x 1920x1080 4:4:4, 8 threads."""
+def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices, entropy):
+    """BASELINE config 4 (one GPU's share, as files): 32 x 1920x1080 4:4:4, 8 threads.  The files
+    carry restart intervals (one per MCU row): with the entropy stage on the host threads
+    (JPEGBLK_GPU_HUFFMAN=0) and on the device (the default for such files)."""
     paths, want = files_1080p
     total = sum((w.size + 255) // 256 * 256 for w in want)
+    if entropy == "host":
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
     for group_mb in (None, "0"):
         if group_mb is None:
             monkeypatch.delenv("JPEGBLK_GROUP_MB", raising=False)
@@ -73,18 +80,26 @@ def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, de
             for _ in range(2):  # second run: buffers, ring and arena are reused
                 imgs, st, tm = dec.run(paths)
                 _check(imgs, st, tm, want)
+            assert dec.device_entropy_images == (2 * len(paths) if entropy == "device" else 0)
 
 
+@pytest.mark.parametrize("entropy", ["host", "device"])
 @pytest.mark.parametrize("devices", [None, [0, 0]])
 @pytest.mark.parametrize("arena", [False, True])
-def test_batch_decoder_config5_8192_420(jb, files_8192, arena, devices):
+def test_batch_decoder_config5_8192_420(jb, files_8192, monkeypatch, arena, devices, entropy):
     """BASELINE config 5 shape: 8192x8192 4:2:0 files (201 MB of coefficients and of pixels per
-    image), restart-interval splitting on (more host threads than files), 8 threads."""
+    image), 8 threads.  Entropy stage on the host -- "host Huffman on all cores overlapped with
+    device IDCT", restart-interval splitting on (more host threads than files) -- and on the device."""
     paths, want = files_8192
     total = sum((w.size + 255) // 256 * 256 for w in want)
+    if entropy == "host":
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
     with jb.BatchDecoder(8, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
         imgs, st, tm = dec.run(paths)
         _check(imgs, st, tm, want)
+        assert dec.device_entropy_images == (len(paths) if entropy == "device" else 0)
     if not arena and devices is None:  # ring back-pressure: 2 threads, ring of 4 slots, 8 submissions
         with jb.BatchDecoder(2, 0) as dec:
             imgs, st, tm = dec.run(paths + paths)
@@ -145,3 +160,30 @@ def test_context_sizes_itself_from_the_frame(jb):
     assert p
     jb.lib().jb_pinned_free(p)
     assert not jb.lib().jb_pinned_alloc_on(99, 1 << 20)
+
+
+def test_batch_decoder_device_entropy_falls_back_per_image(jb, oracle, tmp_path):
+    """A batch of DRI files of one geometry with one damaged file in the middle: the group goes
+    through the device entropy decoder, the damaged image is flagged by its status word and handed to
+    the host decoder (the authority), which rejects it; every other image decodes."""
+    from jpeg_decoder_amd import synth
+    paths, want = _write_files(str(tmp_path), "dri", 640, 360, 2, 2, 9, 3, 10, oracle)
+    data = bytearray(open(paths[4], "rb").read())
+    sos = data.index(b"\xff\xda")
+    for k in range(300, 340):       # garbage inside the scan, marker structure intact
+        if data[sos + k] != 0xff and data[sos + k - 1] != 0xff:
+            data[sos + k] = (data[sos + k] * 7 + 13) % 255
+    open(paths[4], "wb").write(bytes(data))
+    try:
+        jb.entropy_decode(bytes(data))
+        host_accepts = True
+    except jb.JbError:
+        host_accepts = False
+    with jb.BatchDecoder(2, 0) as dec:
+        imgs, st, tm = dec.run(paths)
+        assert dec.device_entropy_images == len(paths)
+    for i in range(len(paths)):
+        if i == 4:
+            assert (st[i] == 0) == host_accepts
+        else:
+            assert st[i] == 0 and np.array_equal(imgs[i], want[i]), i

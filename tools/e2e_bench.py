@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jpeg_decoder_amd as jb  # noqa: E402
 
 
-def make_jpegs(n_distinct, w, h, sub, out_dir):
+def make_jpegs(n_distinct, w, h, sub, out_dir, dri_rows=0):
     from PIL import Image
     paths = []
     rng = np.random.default_rng(1)
@@ -45,20 +45,22 @@ def make_jpegs(n_distinct, w, h, sub, out_dir):
         noise = rng.normal(0, 12, (h // 8 + 1, w // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:h, :w]
         img = np.clip(base * 0.6 + 60 + noise + rng.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
         p = os.path.join(out_dir, f"synth_{w}x{h}_{sub}_{i}.jpg")
-        Image.fromarray(img).save(p, "JPEG", quality=90, subsampling={"444": 0, "420": 2}[sub], optimize=False)
+        kw = {"restart_marker_rows": dri_rows} if dri_rows else {}
+        Image.fromarray(img).save(p, "JPEG", quality=90, subsampling={"444": 0, "420": 2}[sub], optimize=False, **kw)
         paths.append(p)
     return paths
 
 
-def make_jpegs_writer(n_distinct, w, h, sub, out_dir):
+def make_jpegs_writer(n_distinct, w, h, sub, out_dir, dri_rows=0):
     from jpeg_decoder_amd import synth
     hs, vs = {"444": (1, 1), "420": (2, 2), "422": (2, 1), "440": (1, 2)}[sub]
+    ri = dri_rows * ((w + 8 * hs - 1) // (8 * hs))
     paths = []
     for i in range(n_distinct):
         coef, q = synth.synth_blocks(w, h, hs, vs, i)
         p = os.path.join(out_dir, f"writer_{w}x{h}_{sub}_{i}.jpg")
         with open(p, "wb") as f:
-            f.write(synth.encode_jpeg(coef, w, h, hs, vs, q))
+            f.write(synth.encode_jpeg(coef, w, h, hs, vs, q, restart_interval=ri))
         paths.append(p)
     return paths
 
@@ -102,6 +104,8 @@ def main():
     ap.add_argument("--source", default="pil", choices=["pil", "writer"])
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--modes", default="malloc,arena")
+    ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
+                    "restart intervals take the device-side entropy decoder unless JPEGBLK_GPU_HUFFMAN=0")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
@@ -115,7 +119,9 @@ def main():
     out = {"size": args.size, "sampling": args.sub, "n_images": args.n, "host_cpus": os.cpu_count(),
            "cpu_affinity": len(os.sched_getaffinity(0)), "source": args.source}
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d)
+        distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d, args.dri)
+        out["restart_interval_rows"] = args.dri
+        out["JPEGBLK_GPU_HUFFMAN"] = os.environ.get("JPEGBLK_GPU_HUFFMAN", "(default: device for >= 16 intervals)")
         from jpeg_decoder_amd.shard import shard_images
         mine = shard_images(args.n, rank, world)           # image i -> rank i % world
         paths = [distinct[i % len(distinct)] for i in mine]
@@ -147,6 +153,7 @@ def main():
                 # timed: contexts and pinned buffers exist; the first pass hands every image to `check`
                 # (after the decoder's clock has stopped)
                 runs = [dec.run(paths, keep_pixels=False, on_image=check if k == 0 else None) for k in range(args.repeat)]
+                on_device = dec.device_entropy_images
                 assert not bad, f"{mode}/{t} threads: {len(bad)} of {n_mine} images differ from the single-image decode: {bad[:8]}"
                 _, st, tm = min(runs, key=lambda x: x[2]["wall_s"])
                 walls = [round(x[2]["wall_s"], 3) for x in runs]
@@ -161,7 +168,7 @@ def main():
                         "entropy_cpu_s": round(tm["entropy_s"], 3), "submit_wait_s": round(tm["device_s"], 3),
                         "wall_s": round(tm["wall_s"], 3), "walls": walls,
                         "device_busy_fraction": round(n_mine * k_ms * 1e-3 / tm["wall_s"], 4), "n_gpus": world,
-                        "pixels_checked": n_mine})
+                        "pixels_checked": n_mine, "entropy_on_device": bool(on_device)})
         out["decode_path"] = res
         if world > 1:
             if rank == 0:
