@@ -215,8 +215,9 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
  * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (no DRI, markers that do not match
  * the frame, more than two DC or AC tables, progressive ...) -- use jb_entropy_decode.
  * JB_ERR_FORMAT: corrupt data.  jb_decode_file / jb_decode_memory / jb_batch_decoder take this path
- * by themselves for files with 16 or more restart intervals (JPEGBLK_GPU_HUFFMAN=0 turns that
- * off, =1 lowers the threshold to one interval) and fall back to the host decoder otherwise. */
+ * when asked to -- environment JPEGBLK_GPU_HUFFMAN=1: files with 16 or more restart intervals, =2:
+ * any file with DRI -- and fall back to the host decoder per image for whatever it does not take or
+ * flags as corrupt.  The default is the host decoder (north_star's split). */
 int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                              uint16_t *qtabs /* 4*64, may be NULL */, int16_t *d_coef, size_t coef_cap_bytes);
 /* How many images this context has decoded with the entropy stage on the device (through

@@ -259,12 +259,12 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
     bool on_device = false;              // the group's entropy stage ran on the device (jb_huff.hip)
   } grp[kSlots];
-  // Files with restart intervals: the entropy stage runs on the device, this thread only parses,
-  // removes the byte stuffing and packs (JPEGBLK_GPU_HUFFMAN: 0 = never, 1 = from one interval on;
-  // default: 16 intervals or more).  A group is all-device or all-host.
+  // Files with restart intervals can have their entropy stage on the device; this thread then only
+  // parses, removes the byte stuffing and packs.  Opt-in: JPEGBLK_GPU_HUFFMAN=1 (files with 16
+  // intervals or more) or =2 (any file with DRI).  A group is all-device or all-host.
   const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-  const bool dev_entropy = !(knob && knob[0] == '0');
-  const uint32_t min_intervals = (knob && knob[0] == '1') ? 1u : 16u;
+  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2');
+  const uint32_t min_intervals = (knob && knob[0] == '2') ? 1u : 16u;
   std::vector<uint16_t> qtabs;
   auto index_of = [&](int k) { return t + k * r.n_threads; };
   auto report = [&](int i, int st, const std::string &text) {

@@ -368,15 +368,16 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   if (!ctx) return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_memory: ctx is NULL");
   if (!jpeg || !rgb || !width || !height) return jb_fail_(ctx, JB_ERR_NULL, "jb_decode_memory: NULL pointer");
   *rgb = nullptr;
-  // Files with restart intervals: the entropy stage runs on the device too (jb_huff.hip), the host
-  // only parses the headers and removes the byte stuffing.  JPEGBLK_GPU_HUFFMAN=0 keeps it on the
-  // host, =1 takes the device path for any number of intervals (default: 16 or more).  Whatever the
-  // device decoder does not take or flags as corrupt goes through the host decoder below, which
-  // gives the precise answer.
+  // Files with restart intervals can have their entropy stage on the device too (jb_huff.hip): the
+  // host then only parses the headers and removes the byte stuffing.  Opt-in -- JPEGBLK_GPU_HUFFMAN=1
+  // (16 intervals or more) or =2 (any number) -- because one image is at most a few hundred lanes
+  // of serial work: the device decoder wins on batches, not on a single image's latency
+  // (DESIGN.md section 9).  Whatever the device decoder does not take or flags as corrupt goes
+  // through the host decoder below, which gives the precise answer.
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    const uint32_t min_int = (knob && knob[0] == '1') ? 1u : 16u;
-    if (!(knob && knob[0] == '0')) {
+    const uint32_t min_int = (knob && knob[0] == '2') ? 1u : 16u;
+    if (knob && (knob[0] == '1' || knob[0] == '2')) {
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
       if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && job->img.n_int >= min_int) {
         uint8_t *out = (uint8_t *)malloc((size_t)job->geo.rgb_bytes);

@@ -64,13 +64,13 @@ def files_8192(tmp_path_factory, oracle):
 def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices, entropy):
     """BASELINE config 4 (one GPU's share, as files): 32 x 1920x1080 4:4:4, 8 threads.  The files
     carry restart intervals (one per MCU row): with the entropy stage on the host threads
-    (JPEGBLK_GPU_HUFFMAN=0) and on the device (the default for such files)."""
+    (the default) and on the device (JPEGBLK_GPU_HUFFMAN=1)."""
     paths, want = files_1080p
     total = sum((w.size + 255) // 256 * 256 for w in want)
     if entropy == "host":
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
-    else:
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    else:
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     for group_mb in (None, "0"):
         if group_mb is None:
             monkeypatch.delenv("JPEGBLK_GROUP_MB", raising=False)
@@ -93,9 +93,9 @@ def test_batch_decoder_config5_8192_420(jb, files_8192, monkeypatch, arena, devi
     paths, want = files_8192
     total = sum((w.size + 255) // 256 * 256 for w in want)
     if entropy == "host":
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
-    else:
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    else:
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     with jb.BatchDecoder(8, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
         imgs, st, tm = dec.run(paths)
         _check(imgs, st, tm, want)
@@ -162,11 +162,11 @@ def test_context_sizes_itself_from_the_frame(jb):
     assert not jb.lib().jb_pinned_alloc_on(99, 1 << 20)
 
 
-def test_batch_decoder_device_entropy_falls_back_per_image(jb, oracle, tmp_path):
+def test_batch_decoder_device_entropy_falls_back_per_image(jb, oracle, tmp_path, monkeypatch):
     """A batch of DRI files of one geometry with one damaged file in the middle: the group goes
     through the device entropy decoder, the damaged image is flagged by its status word and handed to
     the host decoder (the authority), which rejects it; every other image decodes."""
-    from jpeg_decoder_amd import synth
+    monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     paths, want = _write_files(str(tmp_path), "dri", 640, 360, 2, 2, 9, 3, 10, oracle)
     data = bytearray(open(paths[4], "rb").read())
     sos = data.index(b"\xff\xda")

@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--modes", default="malloc,arena")
     ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
-                    "restart intervals take the device-side entropy decoder unless JPEGBLK_GPU_HUFFMAN=0")
+                    "restart intervals can take the device-side entropy decoder: JPEGBLK_GPU_HUFFMAN=1")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
@@ -121,7 +121,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d, args.dri)
         out["restart_interval_rows"] = args.dri
-        out["JPEGBLK_GPU_HUFFMAN"] = os.environ.get("JPEGBLK_GPU_HUFFMAN", "(default: device for >= 16 intervals)")
+        out["JPEGBLK_GPU_HUFFMAN"] = os.environ.get("JPEGBLK_GPU_HUFFMAN", "(unset: host entropy decoder)")
         from jpeg_decoder_amd.shard import shard_images
         mine = shard_images(args.n, rank, world)           # image i -> rank i % world
         paths = [distinct[i % len(distinct)] for i in mine]

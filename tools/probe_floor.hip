@@ -38,7 +38,8 @@ __global__ __launch_bounds__(T) void mix(const uint8_t *in, uint8_t *out) {
 int main(int argc, char **argv) {
   struct Case { const char *name; long tiles; int rows192; } cases[] = {
       {"1920x1080 4:4:4 x1 (507 tiles)", 507, 16},
-      {"4096x4096 4:2:0 x1 (16384 tiles)", 16384, 32},
+      {"4096x4096 4:2:0 x1 (2048 tiles)", 2048, 32},
+      {"4096x4096 4:2:0 x8 (16384 tiles)", 16384, 32},
       {"679x451 4:2:0 x1 (39 tiles)", 39, 32},
       {"679x451 4:2:0 x512 (19968 tiles)", 19968, 32},
   };
