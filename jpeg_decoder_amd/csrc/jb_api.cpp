@@ -516,6 +516,8 @@ int huff_stage(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int16_
   }
   JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, total, hipMemcpyHostToDevice, up));
   JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)n, up));
+  // the decoder stores non-zero coefficients only
+  JB_HIP(ctx, hipMemsetAsync(d_out, 0, n == 1 ? (size_t)jobs[0]->geo.coef_bytes : (size_t)coef_stride * (size_t)n, up));
   JbHuffLaunch p;
   const uint8_t *d = (const uint8_t *)s.d_blob;
   p.scan = d + off_scan;

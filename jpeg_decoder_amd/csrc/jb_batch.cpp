@@ -205,6 +205,7 @@ struct Totals {
 
 struct Run {
   int device;
+  size_t dev_cap_coef, dev_cap_rgb;  // ring-slot capacity: bounds a group whose entropy stage runs on the device
   const char *const *paths;
   int n_paths, n_threads, inner_threads;
   uint8_t **rgb;
@@ -353,12 +354,18 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int room = (int)(room_c < room_p ? room_c : room_p);
     if (room > kMaxGroup) room = kMaxGroup;
     if (room < 1) room = 1;  // (cannot happen: the capacities cover the largest single image)
+    // a group decoded on the device does not pass through this thread's pinned coefficient buffer:
+    // it is bounded by the ring slot (and, without an arena, by the pinned pixel staging)
+    size_t droom_c = r.dev_cap_coef / coef_bytes, droom_p = (use_arena ? r.dev_cap_rgb : lane->cap_rgb) / rgb_bytes;
+    int room_dev = (int)(droom_c < droom_p ? droom_c : droom_p);
+    if (room_dev > kMaxGroup) room_dev = kMaxGroup;
+    if (room_dev < 1) room_dev = 1;
     // entropy-decode consecutive images of the head's geometry into the slot, back to back -- or,
     // for files with restart intervals, only ready them for the device decoder
     int n = 0;
     bool on_device = false;
     std::vector<std::unique_ptr<JbHuffJob>> jobs;
-    while (n < room && k + n < n_mine) {
+    while (n < (on_device ? room_dev : room) && k + n < n_mine) {
       Parsed &p = parsed[(size_t)(k + n)];
       if (n > 0 && (p.status != JB_OK || !same_geometry(head, p))) break;
       double a = now_s();
@@ -485,8 +492,9 @@ struct jb_batch_decoder {
   }
   // size everything for images of up to (coef, rgb) bytes; page pinning is slow, so the host
   // threads' buffers are created in parallel
-  int ensure_all(size_t need_coef, size_t need_rgb, int n_lanes) {
-    int rc = ensure_ctx(need_coef, need_rgb);
+  int ensure_all(size_t need_coef, size_t need_rgb, int n_lanes, size_t ring_coef = 0, size_t ring_rgb = 0) {
+    // (the ring slots may be larger than the lanes' pinned buffers: groups decoded on the device)
+    int rc = ensure_ctx(ring_coef > need_coef ? ring_coef : need_coef, ring_rgb > need_rgb ? ring_rgb : need_rgb);
     if (rc != JB_OK) return rc;
     const bool with_out = !arena->base;
     std::vector<std::thread> th;
@@ -536,7 +544,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   Shared dev;
-  Run r{d->device, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
+  Run r{d->device, 0, 0, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
         rgb, widths, heights, statuses, d->arena, &dev, &tot};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
@@ -568,8 +576,23 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   }
   if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
   if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
-  int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads) : JB_OK;
+  // With the entropy stage on the device (JPEGBLK_GPU_HUFFMAN) a group should be LARGE: an image is
+  // only as many lanes as it has restart intervals, each a long serial decode, so the device needs
+  // many images per launch to be busy.  The ring slots are sized for such groups
+  // (JPEGBLK_DEV_GROUP_MB, default 128); the threads' pinned buffers keep their size.
+  size_t ring_bytes = 0;
+  {
+    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
+    if (knob && (knob[0] == '1' || knob[0] == '2')) {
+      const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
+      const long mb = e ? atol(e) : 128;
+      ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
+    }
+  }
+  int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads, ring_bytes, ring_bytes) : JB_OK;
   if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
+  r.dev_cap_coef = d->ctx_coef;
+  r.dev_cap_rgb = d->ctx_rgb;
   // pass 2: entropy decoding on the host threads, all submitting to the shared context
   dev.ctx = d->ctx;
   {

@@ -49,7 +49,7 @@ struct JbHuffLaunch {
   int32_t n_wgs;
 };
 
-constexpr int kJbHuffLanes = 128;  // restart intervals per workgroup (LDS: 42 KiB of tables + 128 B per lane < 64 KiB)
+constexpr int kJbHuffLanes = 256;  // restart intervals per workgroup (LDS: 42 KiB of tables + a 64-byte stream ring per lane < 64 KiB)
 // (the launch function is declared in jb_kernels.h: this header stays free of HIP types, the host
 // front end is also built for the CPU alone by tools/fuzz)
 

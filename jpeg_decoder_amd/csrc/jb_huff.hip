@@ -14,14 +14,15 @@
 //
 // Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
 //   LDS: the image's table set (42 KiB: 2 AC pair tables, 2 DC tables, canonical arrays for the
-//   general path) + one 128-byte coefficient block per lane (16 KiB).
+//   general path) + a 128-byte ring of upcoming stream bytes per lane (16 KiB).
 //   The (MCU, block-in-MCU) loops are wave-uniform -- every interval holds the same number of MCUs
 //   but the image's last -- so the component, and with it the table, is uniform per iteration; only
-//   the symbol loop inside a block diverges.  A lane scatters its coefficients into its LDS block
-//   (de-zigzagged, ds_write_b16) and then writes the block out as 128 contiguous bytes: every HBM
-//   line is written whole by one lane, the layout is the fused pixel kernel's input.
-//   The bit stream is read through a 3-dword window per lane (two dwords in use, one prefetched);
-//   a lookup consumes at most 27 bits, so the window advances by at most one dword per step.
+//   the symbol loop inside a block diverges.  The host zeroes the coefficient area (one memset per
+//   submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
+//   into its block's 128-byte line -- the layout is the fused pixel kernel's input.
+//   The bit stream is read through a 3-dword register window per lane (two dwords in use, one
+//   ahead) fed from the lane's LDS ring, which is topped up from HBM at block boundaries (struct
+//   Stream); a lookup consumes at most 27 bits, so the window advances by at most one dword per step.
 // Safety: every stream read is clamped into the image's padded scan; k only grows inside a block
 // (at most 63 iterations); output indices come from host-validated counts.  Corrupt data sets the
 // image's status word and the host re-decodes that image with the serial reader for the precise
@@ -34,18 +35,40 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
+constexpr uint32_t kRing = 64;   // bytes of the stream a lane keeps staged in LDS
+
+// A lane's view of its interval's bit stream.  Bits are taken from a two-dword register window
+// (d0:d1 at bit offset `off`, d2 one dword ahead); the dwords come from a 128-byte ring in LDS that
+// is topped up from HBM in aligned 16-byte chunks at BLOCK boundaries -- a wave-uniform point, and
+// the chunk asked for at one boundary is written into the ring at the next, so its latency is
+// hidden behind a whole block's decoding.  (Fetching per dword from HBM instead put a memory round
+// trip into every iteration of the symbol loop: with 64 lanes in flight some lane crosses a dword
+// in every iteration, and the wave waits for it.)  A block that outruns the ring reads straight
+// from HBM, which is only slower.
 struct Stream {
-  const uint8_t *base;  // the image's clean scan
-  uint32_t limit;       // highest byte offset a 4-byte read may start at (inside the zero padding)
-  uint32_t pos;         // byte offset of the next dword to fetch
-  uint32_t d0, d1, d2;  // window: bits come from d0:d1 at bit offset `off`; d2 is the prefetched next dword
+  const uint8_t *base;  // the image's clean scan (16-byte aligned)
+  uint32_t limit;       // highest byte offset a 16-byte read may start at (inside the zero padding)
+  uint8_t *ring;        // this lane's ring in LDS
+  uint32_t wr;          // the ring holds stream bytes [wr - kRing, wr); multiple of 16
+  uint32_t pos;         // byte offset of the next dword to fetch into the window
+  uint32_t d0, d1, d2;  // window: bits come from d0:d1 at bit offset `off`; d2 is the next dword
   uint32_t off;         // 0..31
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t pend0, pend1; // chunks on their way from HBM (asked for at the previous block boundary)
+  uint32_t npend;       // 0..2
+
+  __device__ __forceinline__ u32x4_t chunk(uint32_t at) const { return *(const u32x4_t *)(base + (at < limit ? at : limit)); }
   __device__ __forceinline__ uint32_t fetch(uint32_t at) const {
-    return bswap32(*(const uint32_t *)(base + (at < limit ? at : limit)));
+    if (at + 4 <= wr) return __builtin_bswap32(*(const uint32_t *)(ring + (at & (kRing - 1))));
+    return __builtin_bswap32(*(const uint32_t *)(base + (at < limit + 12 ? at : limit + 12)));  // past the ring: HBM
   }
   __device__ __forceinline__ void open(uint32_t start) {
+    wr = start & ~15u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *(u32x4_t *)(ring + ((wr + 16u * i) & (kRing - 1))) = chunk(wr + 16u * i);
+    wr += 64;
+    npend = 0;
     pos = start & ~3u;
     off = (start & 3u) * 8u;
     d0 = fetch(pos);
@@ -53,9 +76,31 @@ struct Stream {
     d2 = fetch(pos + 8);
     pos += 12;
   }
+  // block boundary: what was asked for last time goes into the ring, then ask for what fits now
+  __device__ __forceinline__ void top_up() {
+    if (npend >= 1) {
+      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend0;
+      wr += 16;
+    }
+    if (npend >= 2) {
+      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend1;
+      wr += 16;
+    }
+    // a chunk may replace ring bytes [wr - kRing, wr - kRing + 16) once the window has moved past them
+    // (the window's first dword is at pos - 12)
+    npend = 0;
+    if (wr + 16 + 12 <= pos + kRing) {
+      pend0 = chunk(wr);
+      npend = 1;
+      if (wr + 32 + 12 <= pos + kRing) {
+        pend1 = chunk(wr + 16);
+        npend = 2;
+      }
+    }
+  }
   // the next 32 bits of the stream
   __device__ __forceinline__ uint32_t window() const { return (uint32_t)(((((uint64_t)d0) << 32) | d1) << off >> 32); }
-  // n <= 32 - off_before + 1 is not required: any n <= 32 works, the window moves by one dword at most
+  // any n <= 32: the window moves by one dword at most
   __device__ __forceinline__ void consume(uint32_t n) {
     off += n;
     if (off >= 32) {
@@ -101,11 +146,15 @@ __constant__ uint8_t kZigZagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 3
 
 __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunch p) {
   __shared__ __attribute__((aligned(16))) LdsTables lds;
-  __shared__ __attribute__((aligned(16))) uint8_t blocks[kJbHuffLanes * 128];
+  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
   __shared__ uint8_t zz[64];
   const int tid = threadIdx.x;
   const JbHuffWg wg = p.wgs[blockIdx.x];
   const JbHuffImage img = p.images[wg.image];
+  // the table slots of the three components, packed (a dynamically indexed copy of `img` would be
+  // promoted to LDS by the compiler: 12 KiB per workgroup)
+  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
+                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
 
   // the image's table set -> LDS (16-byte copies, the struct is a multiple of 16 bytes)
   {
@@ -128,11 +177,13 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
   }
   Stream s;
   s.base = p.scan + img.scan_off;
-  s.limit = ((img.scan_len + 3u) & ~3u) + 32u;  // inside the >= 64 zero bytes behind the data
+  s.limit = (img.scan_len + 48u) & ~15u;  // a 16-byte read from here still lies inside the 64 zero bytes behind the data
+  s.ring = rings + tid * kRing;
   s.open(start);
 
-  uint8_t *const blk_lds = blocks + tid * 128;
-  const uint32_t sw = ((uint32_t)tid & 7u) << 4;  // chunk swizzle: lane-strided 128-byte rows stay conflict-poor
+  // The coefficient area was zeroed by the host's memset before this launch: a lane only stores the
+  // non-zero coefficients, de-zigzagged, straight into its block's 128-byte line; the L2 gathers a
+  // line's stores before the line leaves for HBM.
   int16_t *out = (int16_t *)((uint8_t *)p.coef + img.coef_off) + (int64_t)iv * img.ri * nb * 64;
   int pred0 = 0, pred1 = 0, pred2 = 0;
   uint32_t err = 0;
@@ -141,11 +192,10 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
     if (__builtin_amdgcn_ballot_w64(mi < count) == 0) break;  // wave-uniform: no lane of this wave has MCUs left
     for (uint32_t b = 0; b < nb; b++) {
       const int c = b < img.ny ? 0 : (int)(b - img.ny) + 1;  // wave-uniform
-      const int dcs = img.dc_slot[c], acs = img.ac_slot[c];
+      const int dcs = (int)((slots >> c) & 1u), acs = (int)((slots >> (4 + c)) & 1u);
       if (mi < count) {
+        s.top_up();
         // ---- one block, as jbe::decode_block_clean does it (reference jpeg.cpp:322-403) ----
-#pragma unroll
-        for (int j = 0; j < 8; j++) *(uint4 *)(blk_lds + (j << 4)) = uint4{0, 0, 0, 0};
         int diff = 0;
         {
           const int32_t fd = lds.t.dcw[dcs][s.window() >> 22];
@@ -167,7 +217,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
         if (c == 0) pred0 = pred;
         else if (c == 1) pred1 = pred;
         else pred2 = pred;
-        *(int16_t *)(blk_lds + (0u ^ sw)) = (int16_t)pred;
+        if (pred) out[0] = (int16_t)pred;
         int k = 1;
         while (k < 64) {
           const uint2 e = *(const uint2 *)&lds.t.pair[acs][s.window() >> 21];
@@ -183,10 +233,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
               err |= 1;
               break;
             }
-            {
-              const uint32_t at = (uint32_t)zz[k] * 2u;
-              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)(hi & 0xffffu);
-            }
+            if (lo & (1u << 18)) out[zz[k]] = (int16_t)(hi & 0xffffu);  // (not for a ZRL: nothing to store)
             k += (int)((lo >> 18) & 1u);
             if (k > 63) {  // the block is complete: what follows belongs to the next block
               s.consume((lo >> 4) & 15u);
@@ -199,10 +246,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
               err |= 1;
               break;
             }
-            {
-              const uint32_t at = (uint32_t)zz[k] * 2u;
-              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)(hi >> 16);  // (a zero onto a zero when there is no second symbol)
-            }
+            if (lo & (1u << 19)) out[zz[k]] = (int16_t)(hi >> 16);  // (not when there is no second symbol, or a ZRL)
             k += (int)((lo >> 19) & 1u);
           } else {  // general path: a code longer than the window, or a run-only symbol
             const int rs = canon_symbol(s, lds.t, 2 + acs);
@@ -222,18 +266,10 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
             if (nbits) {
               const uint32_t v = s.window() >> (32 - nbits);
               s.consume((uint32_t)nbits);
-              const uint32_t at = (uint32_t)zz[k] * 2u;
-              *(int16_t *)(blk_lds + (at ^ sw)) = (int16_t)extend(v, nbits);
+              out[zz[k]] = (int16_t)extend(v, nbits);
               k++;
             }
           }
-        }
-        // ---- the block leaves as 128 contiguous bytes: whole HBM lines, the pixel kernel's layout ----
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-          const u32x4_t v = *(const u32x4_t *)(blk_lds + (((uint32_t)j << 4) ^ sw));
-          __builtin_nontemporal_store(v, (u32x4_t *)out + j);
         }
         out += 64;
       }
