@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,34 @@ struct HuffTable {
     *value = m < (1 << (mag - 1)) ? m - (1 << mag) + 1 : m;
     *run = r, *inc = 1;
     return len + mag;
+  }
+
+  // build() through a small per-thread cache keyed by the DHT content: the files of a batch mostly
+  // carry the same tables (Annex K, or one encoder's), and filling the 2048-entry pair table costs
+  // as much as decoding a few hundred blocks
+  bool build_cached(bool is_ac) {
+    struct Slot {
+      bool used = false, is_ac = false;
+      uint8_t counts[17], symbols[256];
+      std::unique_ptr<HuffTable> built;  // freed when the thread ends
+    };
+    static thread_local Slot cache[8];
+    static thread_local int next = 0;
+    for (Slot &c : cache)
+      if (c.used && c.is_ac == is_ac && memcmp(c.counts, counts, 17) == 0 && memcmp(c.symbols, symbols, 256) == 0) {
+        *this = *c.built;
+        return true;
+      }
+    if (!build(is_ac)) return false;
+    Slot &c = cache[next];
+    next = (next + 1) % 8;
+    if (!c.built) c.built.reset(new HuffTable());
+    *c.built = *this;
+    c.used = true;
+    c.is_ac = is_ac;
+    memcpy(c.counts, counts, 17);
+    memcpy(c.symbols, symbols, 256);
+    return true;
   }
 
   bool build(bool is_ac) {

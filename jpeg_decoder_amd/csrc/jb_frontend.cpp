@@ -136,7 +136,8 @@ int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
         if (total > 256 || i + total > sl) return set_err(e, JB_ERR_FORMAT, "bad DHT segment");
         memcpy(t.symbols, s + i, total);
         i += total;
-        if (!t.build(tc != 0)) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
+        memset(t.symbols + total, 0, (size_t)(256 - total));  // (the cache compares whole arrays)
+        if (!t.build_cached(tc != 0)) return set_err(e, JB_ERR_FORMAT, "over-subscribed Huffman table");
       }
     } else if (m == 0xdd) {  // DRI, reference jpeg.cpp:289-298
       if (sl != 2) return set_err(e, JB_ERR_FORMAT, "bad DRI segment");
@@ -304,6 +305,7 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
       memcpy(job->tables.valptr[at], t[kind]->valptr, sizeof t[kind]->valptr);
       memcpy(job->tables.mincode[at], t[kind]->mincode, sizeof t[kind]->mincode);
       memcpy(job->tables.symbols[at], t[kind]->symbols, 256);
+      memcpy(job->tables.fast[at], t[kind]->fast, sizeof t[kind]->fast);
     }
   }
   static_assert(sizeof(((HuffTable *)nullptr)->pair) == sizeof(((JbHuffTables *)nullptr)->pair[0]), "the device decoder uses the host decoder's AC lookup table");

@@ -17,6 +17,7 @@ struct JbHuffTables {
   int32_t valptr[4][20];
   int32_t mincode[4][20];
   uint8_t symbols[4][256];
+  uint16_t fast[4][512];    // codes of up to 9 bits: (length << 8) | symbol, 0 = longer (jbe::HuffTable::fast)
 };
 
 struct JbHuffImage {

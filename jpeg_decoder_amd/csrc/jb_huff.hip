@@ -13,8 +13,8 @@
 // (images/img4.jpg has DRI = 100) and against the host decoder on writer- and libjpeg-made files.
 //
 // Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
-//   LDS: the image's table set (42 KiB: 2 AC pair tables, 2 DC tables, canonical arrays for the
-//   general path) + a 128-byte ring of upcoming stream bytes per lane (16 KiB).
+//   LDS: the image's table set (46 KiB: 2 AC pair tables, 2 DC tables, the 9-bit tables and
+//   canonical arrays of the general path) + a 64-byte ring of upcoming stream bytes per lane (16 KiB).
 //   The (MCU, block-in-MCU) loops are wave-uniform -- every interval holds the same number of MCUs
 //   but the image's last -- so the component, and with it the table, is uniform per iteration; only
 //   the symbol loop inside a block diverges.  The host zeroes the coefficient area (one memset per
@@ -123,16 +123,25 @@ struct LdsTables {
   JbHuffTables t;
 };
 
-// canonical decode of one symbol (general path: codes longer than the lookup window); -1 = no such code
+// One symbol by itself (the general path: code + magnitude bits longer than the lookup window, or
+// a run-only symbol); -1 = no such code.  No loop: with 64 lanes in flight some lane takes this
+// path in most iterations of the symbol loop and the whole wave walks it, so it is one table lookup
+// for codes of up to 9 bits (the host decoder's `fast` table) and, for the rare longer ones, all
+// seven candidate lengths compared at once (the canonical rule "the first length whose code does not
+// exceed that length's largest code", reference huffman.hpp:17-29 builds the same codes).
 __device__ __forceinline__ int canon_symbol(Stream &s, const JbHuffTables &t, int slot) {
   const uint32_t bits = s.window();
-  int len = 1;
-  int32_t code = (int32_t)(bits >> 31);
-  while (len <= 16 && code > t.maxcode[slot][len]) {
-    len++;
-    code = (int32_t)(bits >> (32 - len));
+  const uint32_t f = t.fast[slot][bits >> 23];
+  if (f) {
+    s.consume(f >> 8);
+    return (int)(f & 0xffu);
   }
+  int len = 17;
+#pragma unroll
+  for (int l = 16; l >= 10; l--)
+    if ((int32_t)(bits >> (32 - l)) <= t.maxcode[slot][l]) len = l;
   if (len > 16) return -1;
+  const int32_t code = (int32_t)(bits >> (32 - len));
   s.consume((uint32_t)len);
   return t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
 }
