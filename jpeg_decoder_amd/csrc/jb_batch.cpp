@@ -579,13 +579,13 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // With the entropy stage on the device (JPEGBLK_GPU_HUFFMAN) a group should be LARGE: an image is
   // only as many lanes as it has restart intervals, each a long serial decode, so the device needs
   // many images per launch to be busy.  The ring slots are sized for such groups
-  // (JPEGBLK_DEV_GROUP_MB, default 128); the threads' pinned buffers keep their size.
+  // (JPEGBLK_DEV_GROUP_MB, default 256); the threads' pinned buffers keep their size.
   size_t ring_bytes = 0;
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
     if (knob && (knob[0] == '1' || knob[0] == '2')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
-      const long mb = e ? atol(e) : 128;
+      const long mb = e ? atol(e) : 256;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
     }
   }

@@ -146,6 +146,15 @@ __device__ __forceinline__ int canon_symbol(Stream &s, const JbHuffTables &t, in
   return t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
 }
 
+// Timing experiments (tools/build_huff_variant.sh, never the product; results are wrong with them):
+//   JBH_NO_STORE    no coefficient stores        JBH_NO_TOPUP  the ring is never topped up (HBM beyond 64 B)
+//   JBH_NO_GENERAL  the general path is an EOB
+#ifdef JBH_NO_STORE
+#define JBH_STORE(lhs, v) ((void)(v))
+#else
+#define JBH_STORE(lhs, v) ((lhs) = (v))
+#endif
+
 __constant__ uint8_t kZigZagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
                                        12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
@@ -203,7 +212,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
       const int c = b < img.ny ? 0 : (int)(b - img.ny) + 1;  // wave-uniform
       const int dcs = (int)((slots >> c) & 1u), acs = (int)((slots >> (4 + c)) & 1u);
       if (mi < count) {
+#ifndef JBH_NO_TOPUP
         s.top_up();
+#endif
         // ---- one block, as jbe::decode_block_clean does it (reference jpeg.cpp:322-403) ----
         int diff = 0;
         {
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
         if (c == 0) pred0 = pred;
         else if (c == 1) pred1 = pred;
         else pred2 = pred;
-        if (pred) out[0] = (int16_t)pred;
+        if (pred) JBH_STORE(out[0], (int16_t)pred);
         int k = 1;
         while (k < 64) {
           const uint2 e = *(const uint2 *)&lds.t.pair[acs][s.window() >> 21];
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
               err |= 1;
               break;
             }
-            if (lo & (1u << 18)) out[zz[k]] = (int16_t)(hi & 0xffffu);  // (not for a ZRL: nothing to store)
+            if (lo & (1u << 18)) JBH_STORE(out[zz[k]], (int16_t)(hi & 0xffffu));  // (not for a ZRL: nothing to store)
             k += (int)((lo >> 18) & 1u);
             if (k > 63) {  // the block is complete: what follows belongs to the next block
               s.consume((lo >> 4) & 15u);
@@ -255,9 +266,12 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
               err |= 1;
               break;
             }
-            if (lo & (1u << 19)) out[zz[k]] = (int16_t)(hi >> 16);  // (not when there is no second symbol, or a ZRL)
+            if (lo & (1u << 19)) JBH_STORE(out[zz[k]], (int16_t)(hi >> 16));  // (not when there is no second symbol, or a ZRL)
             k += (int)((lo >> 19) & 1u);
           } else {  // general path: a code longer than the window, or a run-only symbol
+#ifdef JBH_NO_GENERAL
+            break;
+#endif
             const int rs = canon_symbol(s, lds.t, 2 + acs);
             if (rs < 0) {
               err |= 1;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
             if (nbits) {
               const uint32_t v = s.window() >> (32 - nbits);
               s.consume((uint32_t)nbits);
-              out[zz[k]] = (int16_t)extend(v, nbits);
+              JBH_STORE(out[zz[k]], (int16_t)extend(v, nbits));
               k++;
             }
           }

@@ -240,6 +240,37 @@ def test_front_end_parallel_restart_intervals(jb):
         jb.entropy_decode(bytes(dmg), n_threads=4)
 
 
+def test_front_end_scan_without_eoi_and_alternating_tables(jb):
+    """A buffer that ends right after the last entropy-coded byte (no EOI): the restart-interval
+    threads and the serial path see the same last interval (the last byte used to be dropped from
+    the parallel split).  And the per-thread Huffman table cache: files with different tables
+    decoded alternately on one thread keep decoding to their own coefficients."""
+    from jpeg_decoder_amd import synth
+    w, h = 333, 211
+    coef, q = synth.synth_blocks(w, h, 2, 2, 8)
+    data = synth.encode_jpeg(coef, w, h, 2, 2, q, restart_interval=5)
+    assert data[-2:] == b"\xff\xd9"
+    cut = data[:-2]
+    for t in (1, 4):
+        _, _, c = jb.entropy_decode(cut, n_threads=t)
+        assert np.array_equal(c, coef), t
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(9)
+    img = np.clip(np.cumsum(rng.normal(0, 5, (97, 131, 3)), axis=1) + 128, 0, 255).astype(np.uint8)
+    a = _pil_jpeg(img, quality=85, subsampling=0)                  # Annex K tables
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", quality=85, subsampling=0, optimize=True)   # this file's own tables
+    b = buf.getvalue()
+    assert a[a.index(b"\xff\xc4"):a.index(b"\xff\xda")] != b[b.index(b"\xff\xc4"):b.index(b"\xff\xda")]
+    ca, cb = jb.entropy_decode(a)[2], jb.entropy_decode(b)[2]
+    assert np.array_equal(ca, cb)                                   # same picture, same coefficients
+    for _ in range(3):
+        assert np.array_equal(jb.entropy_decode(a)[2], ca) and np.array_equal(jb.entropy_decode(b)[2], ca)
+        assert np.array_equal(jb.entropy_decode(data)[2], coef)
+
+
 # ---- stream-level round trips through the build's own baseline writer (tools/jpegwriter) ----
 
 def test_annex_k_huffman_tables_match_libjpeg():
