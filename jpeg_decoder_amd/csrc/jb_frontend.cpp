@@ -296,8 +296,6 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   memset(&job->tables, 0, sizeof job->tables);
   for (int slot = 0; slot < 2; slot++) {
     const HuffTable *t[2] = {dc_ids[slot] >= 0 ? &fr->dc[dc_ids[slot]] : nullptr, ac_ids[slot] >= 0 ? &fr->ac[ac_ids[slot]] : nullptr};
-    if (t[0]) memcpy(job->tables.dcw[slot], t[0]->dcw, sizeof t[0]->dcw);
-    if (t[1]) memcpy(job->tables.pair[slot], t[1]->pair, sizeof t[1]->pair);
     for (int kind = 0; kind < 2; kind++) {
       if (!t[kind]) continue;
       const int at = 2 * kind + slot;
@@ -305,11 +303,15 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
       memcpy(job->tables.valptr[at], t[kind]->valptr, sizeof t[kind]->valptr);
       memcpy(job->tables.mincode[at], t[kind]->mincode, sizeof t[kind]->mincode);
       memcpy(job->tables.symbols[at], t[kind]->symbols, 256);
-      memcpy(job->tables.fast[at], t[kind]->fast, sizeof t[kind]->fast);
+      // the code (without magnitude bits) that starts each 11-bit window, from the same canonical arrays
+      uint16_t *win = kind ? job->tables.acl[slot] : job->tables.dcl[slot];
+      for (uint32_t w = 0; w < 2048; w++) {
+        int sym = 0;
+        const int len = t[kind]->window_symbol(w, 11, &sym);
+        win[w] = len ? (uint16_t)((len << 8) | sym) : 0;
+      }
     }
   }
-  static_assert(sizeof(((HuffTable *)nullptr)->pair) == sizeof(((JbHuffTables *)nullptr)->pair[0]), "the device decoder uses the host decoder's AC lookup table");
-  static_assert(sizeof(((HuffTable *)nullptr)->dcw) == sizeof(((JbHuffTables *)nullptr)->dcw[0]), "and its DC lookup table");
   static thread_local CleanScan tls_scan;
   CleanScan &cs = tls_scan;
   unstuff(fr->scan, fr->scan + fr->scan_len, cs);

@@ -6,18 +6,18 @@
 #include <stdint.h>
 
 // One table set: what the scans of one or more images decode with.  Slots 0/1 of each kind; an
-// image maps its three components onto them (JbHuffImage::dc_slot / ac_slot).  The lookup tables
-// are the host decoder's own (jbe::HuffTable::pair / dcw, jb_entropy.h) so that both decoders
-// resolve every code identically; the canonical arrays serve the general path (codes longer than
-// the lookup window).
+// image maps its three components onto them (JbHuffImage::dc_slot / ac_slot).  `acl` / `dcl`
+// resolve a CODE of up to 11 bits from an 11-bit window -- (length << 8) | symbol, 0 = longer -- and
+// the lane takes the magnitude bits that follow out of the same 32-bit window; the canonical
+// arrays (the host decoder's, reference huffman.hpp:17-29 builds the same codes) serve codes of
+// 12..16 bits.  Small on purpose: 18 KiB of LDS per workgroup, so four workgroups fit a CU.
 struct JbHuffTables {
-  uint64_t pair[2][2048];   // AC: up to two run/size symbols + magnitude bits per 11-bit window
-  int32_t dcw[2][1024];     // DC: code + difference bits per 10-bit window
+  uint16_t acl[2][2048];
+  uint16_t dcl[2][2048];
   int32_t maxcode[4][18];   // [0,1] = DC slots, [2,3] = AC slots
   int32_t valptr[4][20];
   int32_t mincode[4][20];
   uint8_t symbols[4][256];
-  uint16_t fast[4][512];    // codes of up to 9 bits: (length << 8) | symbol, 0 = longer (jbe::HuffTable::fast)
 };
 
 struct JbHuffImage {
@@ -50,7 +50,7 @@ struct JbHuffLaunch {
   int32_t n_wgs;
 };
 
-constexpr int kJbHuffLanes = 256;  // restart intervals per workgroup (LDS: 42 KiB of tables + a 64-byte stream ring per lane < 64 KiB)
+constexpr int kJbHuffLanes = 256;  // restart intervals per workgroup (LDS: 18 KiB of tables + a 64-byte stream ring per lane)
 // (the launch function is declared in jb_kernels.h: this header stays free of HIP types, the host
 // front end is also built for the CPU alone by tools/fuzz)
 

@@ -59,9 +59,30 @@ struct Stream {
   uint32_t npend;       // 0..2
 
   __device__ __forceinline__ u32x4_t chunk(uint32_t at) const { return *(const u32x4_t *)(base + (at < limit ? at : limit)); }
+  // The window is fed from LDS ONLY.  (A fetch with an HBM path in it makes d2 "possibly the result
+  // of a global load", and every use of it then waits for vmcnt(0) -- which on gfx950 also means
+  // every coefficient store issued so far: a memory round trip per iteration of the symbol loop.
+  // Measured: 8.5-16 us per block round with that path, against the ~3 us the LDS latencies allow.)
   __device__ __forceinline__ uint32_t fetch(uint32_t at) const {
-    if (at + 4 <= wr) return __builtin_bswap32(*(const uint32_t *)(ring + (at & (kRing - 1))));
-    return __builtin_bswap32(*(const uint32_t *)(base + (at < limit + 12 ? at : limit + 12)));  // past the ring: HBM
+    return __builtin_bswap32(*(const uint32_t *)(ring + (at & (kRing - 1))));
+  }
+  // A block that outruns the ring (more than ~36 bytes of entropy-coded data in one block) refills
+  // it on the spot: rare, and the only place inside a block that waits for HBM.  Replacing the ring's
+  // oldest chunk is safe here: the window (from pos - 12 on) is at the ring's newest bytes.
+  __device__ __forceinline__ void refill_now() {
+    if (npend >= 1) {
+      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend0;
+      wr += 16;
+    }
+    if (npend >= 2) {
+      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend1;
+      wr += 16;
+    }
+    npend = 0;
+    while (pos + 4 > wr) {
+      *(u32x4_t *)(ring + (wr & (kRing - 1))) = chunk(wr);
+      wr += 16;
+    }
   }
   __device__ __forceinline__ void open(uint32_t start) {
     wr = start & ~15u;
@@ -107,6 +128,7 @@ struct Stream {
       off -= 32;
       d0 = d1;
       d1 = d2;
+      if (__builtin_expect(pos + 4 > wr, 0)) refill_now();
       d2 = fetch(pos);
       pos += 4;
     }
