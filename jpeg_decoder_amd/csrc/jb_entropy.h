@@ -34,6 +34,8 @@ struct HuffTable {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
   uint16_t fast[512];
+  // the same over an 11-bit window: what the device-side decoder (jb_huff.hip) resolves codes with
+  uint16_t code11[2048];
   // AC tables: kWideBits-bit lookahead that resolves up to TWO run/size symbols together with their
   // magnitude bits in one step (T.81 F.2.2.1 EXTEND folded in).  The entropy stage is one serial
   // dependency chain per scan -- bit buffer -> index -> table load -> shift -> bit buffer -- so what
@@ -138,6 +140,16 @@ struct HuffTable {
       for (int i = 0; i < counts[len]; i++, k++, code++) {
         const int first = code << (9 - len);
         for (int j = 0; j < (1 << (9 - len)); j++) fast[first + j] = (uint16_t)((len << 8) | symbols[k]);
+      }
+      code <<= 1;
+    }
+    memset(code11, 0, sizeof code11);
+    code = 0;
+    k = 0;
+    for (int len = 1; len <= 11; len++) {
+      for (int i = 0; i < counts[len]; i++, k++, code++) {
+        const int first = code << (11 - len);
+        for (int j = 0; j < (1 << (11 - len)); j++) code11[first + j] = (uint16_t)((len << 8) | symbols[k]);
       }
       code <<= 1;
     }

@@ -303,13 +303,8 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
       memcpy(job->tables.valptr[at], t[kind]->valptr, sizeof t[kind]->valptr);
       memcpy(job->tables.mincode[at], t[kind]->mincode, sizeof t[kind]->mincode);
       memcpy(job->tables.symbols[at], t[kind]->symbols, 256);
-      // the code (without magnitude bits) that starts each 11-bit window, from the same canonical arrays
-      uint16_t *win = kind ? job->tables.acl[slot] : job->tables.dcl[slot];
-      for (uint32_t w = 0; w < 2048; w++) {
-        int sym = 0;
-        const int len = t[kind]->window_symbol(w, 11, &sym);
-        win[w] = len ? (uint16_t)((len << 8) | sym) : 0;
-      }
+      // the code (without magnitude bits) that starts each 11-bit window
+      memcpy(kind ? job->tables.acl[slot] : job->tables.dcl[slot], t[kind]->code11, sizeof t[kind]->code11);
     }
   }
   static thread_local CleanScan tls_scan;

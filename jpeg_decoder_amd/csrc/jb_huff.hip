@@ -6,15 +6,15 @@
 // Why it works: the DC predictors reset at every restart marker (T.81 F.2.1.3.1; reference
 // jpeg.cpp:419-425), so the intervals of a scan are independent bit streams -- after the host has
 // removed the byte stuffing and recorded where each interval starts (jbe::unstuff: memchr speed),
-// interval i is "decode ri MCUs from byte start[i]".  A lane does exactly what the host decoder
-// does for one interval, with the host decoder's own lookup tables (two AC symbols + magnitude
-// bits per 11-bit window, DC code + difference per 10-bit window), so the coefficients are
-// identical by construction; tests pin them against the reference's coefficient dumps
+// interval i is "decode ri MCUs from byte start[i]".  A lane does what the host decoder does for
+// one interval -- the same canonical codes (the host front end's 11-bit code table and canonical
+// arrays), the same EXTEND, the same checks -- one symbol per step; tests pin the coefficients
+// against the reference's coefficient dumps
 // (images/img4.jpg has DRI = 100) and against the host decoder on writer- and libjpeg-made files.
 //
 // Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
-//   LDS: the image's table set (46 KiB: 2 AC pair tables, 2 DC tables, the 9-bit tables and
-//   canonical arrays of the general path) + a 64-byte ring of upcoming stream bytes per lane (16 KiB).
+//   LDS: the image's table set (18 KiB: an 11-bit code table per AC / DC slot + canonical arrays for
+//   longer codes) + a 64-byte ring of upcoming stream bytes per lane (16 KiB): four workgroups per CU.
 //   The (MCU, block-in-MCU) loops are wave-uniform -- every interval holds the same number of MCUs
 //   but the image's last -- so the component, and with it the table, is uniform per iteration; only
 //   the symbol loop inside a block diverges.  The host zeroes the coefficient area (one memset per
@@ -145,32 +145,23 @@ struct LdsTables {
   JbHuffTables t;
 };
 
-// One symbol by itself (the general path: code + magnitude bits longer than the lookup window, or
-// a run-only symbol); -1 = no such code.  No loop: with 64 lanes in flight some lane takes this
-// path in most iterations of the symbol loop and the whole wave walks it, so it is one table lookup
-// for codes of up to 9 bits (the host decoder's `fast` table) and, for the rare longer ones, all
-// seven candidate lengths compared at once (the canonical rule "the first length whose code does not
-// exceed that length's largest code", reference huffman.hpp:17-29 builds the same codes).
-__device__ __forceinline__ int canon_symbol(Stream &s, const JbHuffTables &t, int slot) {
-  const uint32_t bits = s.window();
-  const uint32_t f = t.fast[slot][bits >> 23];
-  if (f) {
-    s.consume(f >> 8);
-    return (int)(f & 0xffu);
-  }
+// A code of 12..16 bits (the 11-bit window table said "longer"): all five candidate lengths compared
+// at once -- the canonical rule "the first length whose code does not exceed that length's largest
+// code" (reference huffman.hpp:17-29 builds the same codes) -- no loop, because with 64 lanes in
+// flight some lane is here in many iterations and the whole wave walks the path.
+// -> (length << 8) | symbol, or 0 when no code matches.
+__device__ __forceinline__ uint32_t long_code(uint32_t bits, const JbHuffTables &t, int slot) {
   int len = 17;
 #pragma unroll
-  for (int l = 16; l >= 10; l--)
+  for (int l = 16; l >= 12; l--)
     if ((int32_t)(bits >> (32 - l)) <= t.maxcode[slot][l]) len = l;
-  if (len > 16) return -1;
+  if (len > 16) return 0;
   const int32_t code = (int32_t)(bits >> (32 - len));
-  s.consume((uint32_t)len);
-  return t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
+  return ((uint32_t)len << 8) | t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
 }
 
 // Timing experiments (tools/build_huff_variant.sh, never the product; results are wrong with them):
-//   JBH_NO_STORE    no coefficient stores        JBH_NO_TOPUP  the ring is never topped up (HBM beyond 64 B)
-//   JBH_NO_GENERAL  the general path is an EOB
+//   JBH_NO_STORE    no coefficient stores        JBH_NO_TOPUP  the ring is only refilled when it runs dry
 #ifdef JBH_NO_STORE
 #define JBH_STORE(lhs, v) ((void)(v))
 #else
@@ -237,21 +228,22 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
 #ifndef JBH_NO_TOPUP
         s.top_up();
 #endif
-        // ---- one block, as jbe::decode_block_clean does it (reference jpeg.cpp:322-403) ----
+        // ---- one block: what reference decodeMCUComponent does (jpeg.cpp:322-403), same results as
+        // the host decoder's decode_block_clean.  Every symbol is ONE step of the same shape -- code
+        // from the 11-bit window table, magnitude bits out of the same 32-bit window, one consume,
+        // one predicated store -- so the lanes of a wave differ in how many steps they take, not
+        // in which path they are on.
         int diff = 0;
         {
-          const int32_t fd = lds.t.dcw[dcs][s.window() >> 22];
-          if (fd) {
-            s.consume((uint32_t)(fd & 0xff));
-            diff = fd >> 8;
+          const uint32_t bits = s.window();
+          uint32_t t = lds.t.dcl[dcs][bits >> 21];
+          if (t == 0) t = long_code(bits, lds.t, dcs);
+          const uint32_t len = t >> 8, sz = t & 0xffu;
+          if (t == 0 || sz > 11) {
+            err |= 1;
           } else {
-            const int sym = canon_symbol(s, lds.t, dcs);
-            if (sym < 0 || sym > 11) err |= 1;
-            else if (sym) {
-              const uint32_t v = s.window() >> (32 - sym);
-              s.consume((uint32_t)sym);
-              diff = extend(v, sym);
-            }
+            if (sz) diff = extend((bits << len) >> (32 - sz), (int)sz);  // len + sz <= 27 bits of the 32
+            s.consume(len + sz);
           }
         }
         int pred = (c == 0 ? pred0 : c == 1 ? pred1 : pred2) + diff;
@@ -261,60 +253,20 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
         else pred2 = pred;
         if (pred) JBH_STORE(out[0], (int16_t)pred);
         int k = 1;
-        while (k < 64) {
-          const uint2 e = *(const uint2 *)&lds.t.pair[acs][s.window() >> 21];
-          const uint32_t lo = e.x, hi = e.y;
-          const uint32_t n = lo & 15u;
-          if (n) {  // up to two symbols, magnitude bits included, resolved by one lookup
-            if (lo & (1u << 20)) {  // EOB
-              s.consume(n);
-              break;
-            }
-            k += (int)((lo >> 8) & 31u);
-            if (k > 63) {
-              err |= 1;
-              break;
-            }
-            if (lo & (1u << 18)) JBH_STORE(out[zz[k]], (int16_t)(hi & 0xffffu));  // (not for a ZRL: nothing to store)
-            k += (int)((lo >> 18) & 1u);
-            if (k > 63) {  // the block is complete: what follows belongs to the next block
-              s.consume((lo >> 4) & 15u);
-              break;
-            }
-            s.consume(n);
-            if (lo & (1u << 21)) break;  // the second symbol is EOB
-            k += (int)((lo >> 13) & 31u);
-            if (k > 63) {
-              err |= 1;
-              break;
-            }
-            if (lo & (1u << 19)) JBH_STORE(out[zz[k]], (int16_t)(hi >> 16));  // (not when there is no second symbol, or a ZRL)
-            k += (int)((lo >> 19) & 1u);
-          } else {  // general path: a code longer than the window, or a run-only symbol
-#ifdef JBH_NO_GENERAL
-            break;
-#endif
-            const int rs = canon_symbol(s, lds.t, 2 + acs);
-            if (rs < 0) {
-              err |= 1;
-              break;
-            }
-            if (rs == 0) break;  // EOB
-            int r = rs >> 4;
-            const int nbits = rs & 15;
-            if (rs == 0xf0) r = 16;
-            if (k + r >= 64 || nbits > 10) {  // reference jpeg.cpp:372-385
-              err |= 1;
-              break;
-            }
-            k += r;
-            if (nbits) {
-              const uint32_t v = s.window() >> (32 - nbits);
-              s.consume((uint32_t)nbits);
-              JBH_STORE(out[zz[k]], (int16_t)extend(v, nbits));
-              k++;
-            }
-          }
+        bool done = false;
+        while (!done) {
+          const uint32_t bits = s.window();
+          uint32_t t = lds.t.acl[acs][bits >> 21];
+          if (t == 0) t = long_code(bits, lds.t, 2 + acs);
+          const uint32_t len = t >> 8, rs = t & 0xffu, sz = rs & 15u;
+          const bool eob = rs == 0;
+          k += rs == 0xf0u ? 16 : (int)(rs >> 4);  // (a ZRL, or the run of a run/size symbol; 0 for EOB)
+          const bool bad = t == 0 || (!eob && (k > 63 || sz > 10));  // reference jpeg.cpp:372-385
+          if (sz && !bad) JBH_STORE(out[zz[k & 63]], (int16_t)extend((bits << len) >> (32 - sz), (int)sz));
+          k += sz ? 1 : 0;
+          if (!bad) s.consume(len + sz);  // <= 16 + 10 bits of the 32
+          err |= bad ? 1u : 0u;
+          done = eob || bad || k > 63;
         }
         out += 64;
       }
