@@ -36,6 +36,7 @@ struct Slot {
   // device-side entropy decoding (jb_huff.hip): the submission's packed scans, interval tables and
   // Huffman table sets (pinned host copy + device copy), and one status word per image
   uint8_t *h_blob = nullptr;
+  size_t h_blob_cap = 0;
   void *d_blob = nullptr;
   size_t blob_cap = 0;
   uint32_t *h_status = nullptr;  // pinned, kMaxBatch words
@@ -467,40 +468,15 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
 }
 
 // ---- device-side entropy decoding (jb_huff.hip) -------------------------------------------------
-// Pack the submission's images for the device decoder into the slot's pinned blob --
-//   [JbHuffImage x n][JbHuffWg x n_wg][JbHuffTables x n_sets][starts][scans, 16-byte aligned each]
-// -- upload it in one copy and launch the decoder: image i's coefficient blocks land at
-// d_out + i * coef_stride bytes, its status word at s.d_status[i].  Table sets are shared by the
-// images that use identical tables (the usual case: one set for the whole submission).
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-int huff_stage(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int16_t *d_out, int64_t coef_stride, hipStream_t up) {
-  std::vector<int> set_of((size_t)n, 0);
-  std::vector<int> sets;  // index of the first job that owns each distinct table set
-  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
-  for (int i = 0; i < n; i++) {
-    int found = -1;
-    for (size_t k = 0; k < sets.size() && found < 0; k++)
-      if (memcmp(&jobs[sets[k]]->tables, &jobs[i]->tables, sizeof(JbHuffTables)) == 0) found = (int)k;
-    if (found < 0) {
-      found = (int)sets.size();
-      sets.push_back(i);
-    }
-    set_of[(size_t)i] = found;
-    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
-    n_starts += jobs[i]->starts.size();
-    scan_bytes += align16(jobs[i]->scan.size());
-  }
-  const size_t off_img = 0, off_wg = align16(off_img + (size_t)n * sizeof(JbHuffImage)),
-               off_tab = align16(off_wg + n_wg * sizeof(JbHuffWg)), off_starts = off_tab + sets.size() * sizeof(JbHuffTables),
-               off_scan = align16(off_starts + n_starts * 4), total = off_scan + scan_bytes;
-  if (total > 0xffffff00u || n_wg > 0x7fffffffu) return fail(ctx, JB_ERR_CAPACITY, "submission too large for the device entropy decoder");
-  if (total > s.blob_cap) {  // (the slot is idle: its previous submission has been waited for)
-    if (s.h_blob) (void)hipHostFree(s.h_blob);
+// upload a packed submission (jb_huff_pack_) and launch the decoder: image i's coefficient blocks
+// land at d_out + i * coef_stride bytes, its status word at s.d_status[i]
+int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up) {
+  if (lay.total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
     if (s.d_blob) (void)hipFree(s.d_blob);
-    s.h_blob = nullptr, s.d_blob = nullptr, s.blob_cap = 0;
-    const size_t cap = total + total / 4 + 65536;
-    JB_HIP(ctx, hipHostMalloc((void **)&s.h_blob, cap, hipHostMallocDefault));
+    s.d_blob = nullptr, s.blob_cap = 0;
+    const size_t cap = lay.total + lay.total / 4 + 65536;
     JB_HIP(ctx, hipMalloc(&s.d_blob, cap));
     s.blob_cap = cap;
   }
@@ -508,53 +484,51 @@ int huff_stage(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int16_
     JB_HIP(ctx, hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault));
     JB_HIP(ctx, hipMalloc((void **)&s.d_status, 4 * 256));
   }
-  uint8_t *const h = s.h_blob;
-  JbHuffImage *im = (JbHuffImage *)(h + off_img);
-  JbHuffWg *wg = (JbHuffWg *)(h + off_wg);
-  uint32_t *st = (uint32_t *)(h + off_starts);
-  size_t w = 0, si = 0, sc = off_scan;
-  for (size_t k = 0; k < sets.size(); k++) memcpy(h + off_tab + k * sizeof(JbHuffTables), &jobs[sets[k]]->tables, sizeof(JbHuffTables));
-  for (int i = 0; i < n; i++) {
-    const JbHuffJob &j = *jobs[i];
-    if ((int64_t)j.geo.coef_bytes > coef_stride && n > 1) return fail(ctx, JB_ERR_CAPACITY, "coefficient stride smaller than an image");
-    im[i] = j.img;
-    im[i].scan_off = (uint32_t)(sc - off_scan);
-    im[i].int_off = (uint32_t)si;
-    im[i].table_set = (uint32_t)set_of[(size_t)i];
-    im[i].coef_off = (int64_t)i * coef_stride;
-    for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
-    memcpy(st + si, j.starts.data(), j.starts.size() * 4);
-    si += j.starts.size();
-    memcpy(h + sc, j.scan.data(), j.scan.size());
-    sc += align16(j.scan.size());
-  }
-  JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, total, hipMemcpyHostToDevice, up));
-  JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)n, up));
+  JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, lay.total, hipMemcpyHostToDevice, up));
+  JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)lay.n, up));
   // the decoder stores non-zero coefficients only
-  JB_HIP(ctx, hipMemsetAsync(d_out, 0, n == 1 ? (size_t)jobs[0]->geo.coef_bytes : (size_t)coef_stride * (size_t)n, up));
+  JB_HIP(ctx, hipMemsetAsync(d_out, 0, zero_bytes, up));
   JbHuffLaunch p;
   const uint8_t *d = (const uint8_t *)s.d_blob;
-  p.scan = d + off_scan;
-  p.starts = (const uint32_t *)(d + off_starts);
-  p.tables = (const JbHuffTables *)(d + off_tab);
-  p.images = (const JbHuffImage *)(d + off_img);
-  p.wgs = (const JbHuffWg *)(d + off_wg);
+  p.scan = d + lay.off_scan;
+  p.starts = (const uint32_t *)(d + lay.off_starts);
+  p.tables = (const JbHuffTables *)(d + lay.off_tab);
+  p.images = (const JbHuffImage *)(d + lay.off_img);
+  p.wgs = (const JbHuffWg *)(d + lay.off_wg);
   p.coef = d_out;
   p.status = s.d_status;
-  p.n_wgs = (int32_t)n_wg;
+  p.n_wgs = (int32_t)lay.n_wg;
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
+}
+
+// the slot's own pinned staging for callers that did not pack themselves (single images)
+int pack_into_slot(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, int64_t coef_stride, JbHuffLayout *lay) {
+  const size_t need = jb_huff_pack_size_(jobs, n);
+  if (need > s.h_blob_cap) {
+    if (s.h_blob) (void)hipHostFree(s.h_blob);
+    s.h_blob = nullptr, s.h_blob_cap = 0;
+    const size_t cap = need + need / 4 + 65536;
+    JB_HIP(ctx, hipHostMalloc((void **)&s.h_blob, cap, hipHostMallocDefault));
+    s.h_blob_cap = cap;
+  }
+  const int rc = jb_huff_pack_(jobs, n, coef_stride, s.h_blob, lay);
+  return rc ? fail(ctx, rc, "submission too large for the device entropy decoder") : JB_OK;
 }
 
 // One submission whose coefficients are produced ON the device: n images of one geometry, each a
 // prepared JbHuffJob.  Same ring, same ordering and same download as submit_impl; what is uploaded
 // is the compressed scan (a tenth of the coefficients), and the status words come back with the
 // pixels.  jb_wait / jb_poll report JB_ERR_FORMAT when the decoder met corrupt data.
-int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, uint8_t *rgb, int64_t rgb_stride,
+// Either `jobs` (packed here, into the slot's pinned staging) or a blob the caller packed itself
+// (`packed` + `lay`, pinned, valid until the submission has completed) with the images' descriptor
+// and tables (`desc`, `qtabs` = n x 4*64).
+int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *packed, const JbHuffLayout *lay_in,
+                     const jb_image_desc *desc_in, const uint16_t *qtabs_in, int n_images, uint8_t *rgb, int64_t rgb_stride,
                      uint32_t *status_out, int *ticket) {
   if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
   if (n_images < 1 || n_images > kMaxBatch) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d outside 1..%d", n_images, kMaxBatch);
-  const jb_image_desc *desc = &jobs[0]->desc;
+  const jb_image_desc *desc = jobs ? &jobs[0]->desc : desc_in;
   jb_geometry g;
   int rc = check_desc(ctx, desc, &g);
   if (rc) return rc;
@@ -575,11 +549,19 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, int n_images, ui
   if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   hipStream_t up = ps, down = ps;
   for (int i = 0; i < n_images; i++) {
-    rc = jb_resolve_qtabs(&jobs[i]->desc, jobs[i]->qtabs, s.h_q + (size_t)i * 192);
+    rc = jb_resolve_qtabs(desc, jobs ? jobs[i]->qtabs : qtabs_in + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
   }
   JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768u * (size_t)n_images, hipMemcpyHostToDevice, up));
-  rc = huff_stage(ctx, s, jobs, n_images, (int16_t *)s.d_coef, g.coef_bytes, up);
+  JbHuffLayout lay_own;
+  if (jobs) {
+    rc = pack_into_slot(ctx, s, jobs, n_images, g.coef_bytes, &lay_own);
+    if (rc) return rc;
+    packed = s.h_blob;
+    lay_in = &lay_own;
+  }
+  if (lay_in->n != n_images || lay_in->coef_stride != g.coef_bytes) return fail(ctx, JB_ERR_STATE, "packed submission does not match its descriptor");
+  rc = huff_stage(ctx, s, packed, *lay_in, coef_total, (int16_t *)s.d_coef, up);
   if (rc) return rc;
   jb_device_batch b;
   memset(&b, 0, sizeof b);
@@ -649,8 +631,12 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
   DeviceGuard guard(ctx->device);
   Slot &s = ctx->huff_aux;
   const JbHuffJob *jobs[1] = {job};
-  rc = huff_stage(ctx, s, jobs, 1, d_coef, job->geo.coef_bytes, ctx->stream);
-  delete job;  // (huff_stage copied everything into the pinned blob)
+  JbHuffLayout lay;
+  rc = pack_into_slot(ctx, s, jobs, 1, job->geo.coef_bytes, &lay);
+  const size_t coef_bytes = (size_t)job->geo.coef_bytes;
+  delete job;  // (everything it held is in the pinned blob now)
+  if (rc) return rc;
+  rc = huff_stage(ctx, s, s.h_blob, lay, coef_bytes, d_coef, ctx->stream);
   if (rc) return rc;
   JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -665,14 +651,15 @@ int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_
   if (rc) return rc;
   int ticket = -1;
   const JbHuffJob *jobs[1] = {job};
-  rc = submit_jobs_impl(ctx, jobs, 1, rgb, rgb_stride, nullptr, &ticket);
+  rc = submit_jobs_impl(ctx, jobs, nullptr, nullptr, nullptr, nullptr, 1, rgb, rgb_stride, nullptr, &ticket);
   if (rc) return rc;
   return jb_wait(ctx, ticket);
 }
 
 // several prepared images of ONE geometry in one submission (jb_batch.cpp); pixels contiguous, tight rows
-int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, uint32_t *status_out, int *ticket) {
-  return submit_jobs_impl(ctx, jobs, n, rgb, 3LL * jobs[0]->desc.width, status_out, ticket);
+int jb_submit_packed_(jb_ctx *ctx, const jb_image_desc *desc, const uint16_t *qtabs, const uint8_t *packed, const JbHuffLayout *lay,
+                      uint8_t *rgb, uint32_t *status_out, int *ticket) {
+  return submit_jobs_impl(ctx, nullptr, packed, lay, desc, qtabs, lay->n, rgb, 3LL * desc->width, status_out, ticket);
 }
 
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,
@@ -857,3 +844,64 @@ void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d) { ctx->last_desc
 
 // used by jb_frontend.cpp to report through the same channel
 int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%s", msg); }
+
+// ---- packing of device-entropy submissions: pure host code (see jb_huff.h) ----------------------
+size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n) {
+  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
+  for (int i = 0; i < n; i++) {
+    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_starts += jobs[i]->starts.size();
+    scan_bytes += ((jobs[i]->scan.size() + 15) & ~(size_t)15);
+  }
+  return (size_t)n * sizeof(JbHuffImage) + n_wg * sizeof(JbHuffWg) + (size_t)n * sizeof(JbHuffTables) + n_starts * 4 + scan_bytes + 64;
+}
+
+int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint8_t *h, JbHuffLayout *lay) {
+  auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  std::vector<int> set_of((size_t)n, 0);
+  std::vector<int> sets;  // index of the first job that owns each distinct table set
+  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
+  for (int i = 0; i < n; i++) {
+    int found = -1;
+    for (size_t k = 0; k < sets.size() && found < 0; k++)
+      if (memcmp(&jobs[sets[k]]->tables, &jobs[i]->tables, sizeof(JbHuffTables)) == 0) found = (int)k;
+    if (found < 0) {
+      found = (int)sets.size();
+      sets.push_back(i);
+    }
+    set_of[(size_t)i] = found;
+    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_starts += jobs[i]->starts.size();
+    scan_bytes += a16(jobs[i]->scan.size());
+    if (n > 1 && (int64_t)jobs[i]->geo.coef_bytes > coef_stride) return JB_ERR_CAPACITY;
+  }
+  lay->off_img = 0;
+  lay->off_wg = a16((size_t)n * sizeof(JbHuffImage));
+  lay->off_tab = a16(lay->off_wg + n_wg * sizeof(JbHuffWg));
+  lay->off_starts = lay->off_tab + sets.size() * sizeof(JbHuffTables);
+  lay->off_scan = a16(lay->off_starts + n_starts * 4);
+  lay->total = lay->off_scan + scan_bytes;
+  lay->n = n;
+  lay->n_wg = (int)n_wg;
+  lay->coef_stride = coef_stride;
+  if (lay->total > 0xffffff00u || n_wg > 0x7fffffffu) return JB_ERR_CAPACITY;
+  JbHuffImage *im = (JbHuffImage *)(h + lay->off_img);
+  JbHuffWg *wg = (JbHuffWg *)(h + lay->off_wg);
+  uint32_t *st = (uint32_t *)(h + lay->off_starts);
+  size_t w = 0, si = 0, sc = lay->off_scan;
+  for (size_t k = 0; k < sets.size(); k++) memcpy(h + lay->off_tab + k * sizeof(JbHuffTables), &jobs[sets[k]]->tables, sizeof(JbHuffTables));
+  for (int i = 0; i < n; i++) {
+    const JbHuffJob &j = *jobs[i];
+    im[i] = j.img;
+    im[i].scan_off = (uint32_t)(sc - lay->off_scan);
+    im[i].int_off = (uint32_t)si;
+    im[i].table_set = (uint32_t)set_of[(size_t)i];
+    im[i].coef_off = (int64_t)i * coef_stride;
+    for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
+    memcpy(st + si, j.starts.data(), j.starts.size() * 4);
+    si += j.starts.size();
+    memcpy(h + sc, j.scan.data(), j.scan.size());
+    sc += a16(j.scan.size());
+  }
+  return JB_OK;
+}

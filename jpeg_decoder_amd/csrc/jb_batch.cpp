@@ -33,7 +33,8 @@ struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
 // device-side entropy decoding: several prepared images of one geometry in one submission; the
 // images' status words (0 = decoded cleanly) are copied to `status_out` (pinned) with the pixels
-extern "C" int jb_submit_jobs_(jb_ctx *ctx, const JbHuffJob *const *jobs, int n, uint8_t *rgb, uint32_t *status_out, int *ticket);
+extern "C" int jb_submit_packed_(jb_ctx *ctx, const jb_image_desc *desc, const uint16_t *qtabs, const uint8_t *packed,
+                                 const JbHuffLayout *lay, uint8_t *rgb, uint32_t *status_out, int *ticket);
 // jb_wait in two halves, so that many threads can wait on one shared context (jb_api.cpp):
 // under the caller's lock, the event to block on (nullptr: the submission has completed) ...
 void *jb_wait_begin_(jb_ctx *ctx, int ticket);
@@ -125,6 +126,18 @@ struct Lane {
   int16_t *coef[kSlots] = {nullptr, nullptr};
   uint8_t *out[kSlots] = {nullptr, nullptr};
   uint32_t *status[kSlots] = {nullptr, nullptr};  // per image of a group decoded on the device: its status word
+  uint8_t *blob[kSlots] = {nullptr, nullptr};     // pinned: a device-entropy group packed for upload (jb_huff_pack_)
+  size_t blob_cap[kSlots] = {0, 0};
+  int device_of_blobs = 0;
+  uint8_t *ensure_blob(int device, int s, size_t need) {
+    if (need <= blob_cap[s]) return blob[s];
+    jb_pinned_free(blob[s]);
+    blob_cap[s] = 0;
+    const size_t cap = need + need / 4 + 65536;
+    blob[s] = (uint8_t *)jb_pinned_alloc_on(device, cap);
+    if (blob[s]) blob_cap[s] = cap;
+    return blob[s];
+  }
   size_t cap_coef = 0, cap_rgb = 0;
   bool has_out = false;
 
@@ -170,6 +183,9 @@ struct Lane {
       coef[s] = nullptr;
       jb_pinned_free(status[s]);
       status[s] = nullptr;
+      jb_pinned_free(blob[s]);
+      blob[s] = nullptr;
+      blob_cap[s] = 0;
     }
     drop_out();
     cap_coef = cap_rgb = 0;
@@ -427,15 +443,26 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
         }
       }
     }
+    JbHuffLayout lay;
+    if (st == JB_OK && on_device) {  // pack the group into this thread's pinned blob -- outside the shared lock
+      std::vector<const JbHuffJob *> ptrs;
+      for (auto &j : jobs) ptrs.push_back(j.get());
+      uint8_t *blob = lane->ensure_blob(r.device, s, jb_huff_pack_size_(ptrs.data(), n));
+      if (!blob) {
+        st = JB_ERR_HIP;
+        text = "pinned host allocation failed";
+      } else if ((st = jb_huff_pack_(ptrs.data(), n, (int64_t)coef_bytes, blob, &lay)) != JB_OK) {
+        text = "submission too large for the device entropy decoder";
+      }
+      jobs.clear();  // (everything the jobs held is in the blob now)
+    }
     if (st == JB_OK) {
       double a = now_s();
       // every copy of the submission is pinned <-> device, so this returns at once and the
       // transfers and the kernel run while this thread decodes its next group
       std::lock_guard<std::mutex> lk(r.dev->mu);
       if (on_device) {
-        std::vector<const JbHuffJob *> ptrs;
-        for (auto &j : jobs) ptrs.push_back(j.get());
-        st = jb_submit_jobs_(r.dev->ctx, ptrs.data(), n, dst, lane->status[s], &grp[s].ticket);
+        st = jb_submit_packed_(r.dev->ctx, &head.desc, qtabs.data(), lane->blob[s], &lay, dst, lane->status[s], &grp[s].ticket);
       } else {
         st = jb_submit_batch(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
       }

@@ -76,3 +76,17 @@ struct JbHuffJob {
 // DC or AC tables in use, a frame for the general front end) -- use the host decoder.  Other
 // negatives: the header errors of jb_entropy_decode.
 int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err);
+
+// Where the pieces of a packed submission lie in its blob:
+//   [JbHuffImage x n][JbHuffWg x n_wg][JbHuffTables x n_sets][starts][scans, 16-byte aligned each]
+// Table sets are shared by the images that use identical tables (the usual case: one set).
+struct JbHuffLayout {
+  size_t off_img = 0, off_wg = 0, off_tab = 0, off_starts = 0, off_scan = 0, total = 0;
+  int n = 0, n_wg = 0;
+  int64_t coef_stride = 0;
+};
+// Upper bound of the blob size for these jobs; and the packing itself (pure host code, no HIP: the
+// batch decoder's threads pack into their own pinned buffers WITHOUT holding the shared context's
+// lock -- twelve megabytes of memcpy per group under that lock serialised the whole decoder).
+size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n);
+int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint8_t *dst, JbHuffLayout *lay);
