@@ -57,8 +57,8 @@ struct jb_ctx {
   // Submissions whose entropy stage runs on the device: a decoder launch is latency-bound (a lane
   // walks its interval's blocks one after the other: milliseconds, whatever the group size), so
   // several of them must be in flight at once; each such submission runs whole on one of these.
-  static constexpr int kPool = 8;
-  hipStream_t pool[kPool] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kPool = 16;
+  hipStream_t pool[kPool] = {};
   unsigned n_group_submits = 0;
   size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
   int n_slots = 0;
@@ -425,10 +425,18 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   // submitters that overlaps uploads and downloads just as well, without a cross-stream event per
   // group (measured with 16 host threads on 679x451 images: 14,500 images/s with the event,
   // 24,700 with every group on one stream, 38,400 alternating).
-  // the whole submission on one stream of the pool, consecutive submissions on different ones
-  hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
-  if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-  hipStream_t up = ps, down = ps;
+  hipStream_t up = ctx->stream, down = ctx->stream2 ? ctx->stream2 : ctx->stream;
+  if (n_images > 1) {
+    if (ctx->stream2 && (ctx->n_group_submits++ & 1u)) up = ctx->stream2;
+    down = up;
+  }
+  // JPEGBLK_HOST_POOL=1 (A/B knob): every submission whole on one of the pool streams instead
+  static const bool host_pool = getenv("JPEGBLK_HOST_POOL") && getenv("JPEGBLK_HOST_POOL")[0] == '1';
+  if (host_pool) {
+    hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
+    if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    up = down = ps;
+  }
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, qtabs + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
