@@ -59,6 +59,14 @@ struct jb_ctx {
   // several of them must be in flight at once; each such submission runs whole on one of these.
   static constexpr int kPool = 16;
   hipStream_t pool[kPool] = {};
+  // Single-image submissions of host coefficients: K independent (upload + kernel, download) stream
+  // pairs used in turn -- pair 0 is (stream, stream2).  Within a pair the download of image i
+  // overlaps the upload of image i + K (the link runs both ways); across pairs the chains of
+  // different submitters do not queue behind each other.
+  static constexpr int kMaxPairs = 8;
+  int n_pairs = 1;
+  hipStream_t pair_up[kMaxPairs] = {}, pair_down[kMaxPairs] = {};
+  unsigned n_single_submits = 0;
   unsigned n_group_submits = 0;
   size_t max_coef = 0, max_rgb = 0, rgb_alloc = 0;
   int n_slots = 0;
@@ -173,6 +181,11 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   ctx->rgb_alloc = max_rgb_bytes ? (size_t)round_up((int64_t)max_rgb_bytes, 256) : 0;  // device rows are tightly packed
   ctx->n_slots = max_coef_bytes ? n_slots : 0;
   ctx->n_slots_req = n_slots;
+  if (const char *e = getenv("JPEGBLK_STREAM_PAIRS")) {  // A/B knob
+    ctx->n_pairs = atoi(e);
+    if (ctx->n_pairs < 1) ctx->n_pairs = 1;
+    if (ctx->n_pairs > jb_ctx::kMaxPairs) ctx->n_pairs = jb_ctx::kMaxPairs;
+  }
   DeviceGuard guard(device_id);
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -197,6 +210,13 @@ void jb_ctx_destroy(jb_ctx *ctx) {
       (void)hipStreamDestroy(ps);
       ps = nullptr;
     }
+  for (int k = 1; k < jb_ctx::kMaxPairs; k++)
+    for (hipStream_t *ps : {&ctx->pair_up[k], &ctx->pair_down[k]})
+      if (*ps) {
+        (void)hipStreamSynchronize(*ps);
+        (void)hipStreamDestroy(*ps);
+        *ps = nullptr;
+      }
   for (int i = 0; i < 64; i++) {
     Slot &s = ctx->slots[i];
     if (s.d_coef) (void)hipFree(s.d_coef);
@@ -233,6 +253,10 @@ int jb_ctx_synchronize(jb_ctx *ctx) {
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
     if (ps) JB_HIP(ctx, hipStreamSynchronize(ps));
+  for (int k = 1; k < jb_ctx::kMaxPairs; k++) {
+    if (ctx->pair_up[k]) JB_HIP(ctx, hipStreamSynchronize(ctx->pair_up[k]));
+    if (ctx->pair_down[k]) JB_HIP(ctx, hipStreamSynchronize(ctx->pair_down[k]));
+  }
   return JB_OK;
 }
 
@@ -311,6 +335,10 @@ int jb_ctx_reserve(jb_ctx *ctx, size_t max_coef_bytes, size_t max_rgb_bytes) {
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
     if (ps) JB_HIP(ctx, hipStreamSynchronize(ps));
+  for (int k = 1; k < jb_ctx::kMaxPairs; k++) {
+    if (ctx->pair_up[k]) JB_HIP(ctx, hipStreamSynchronize(ctx->pair_up[k]));
+    if (ctx->pair_down[k]) JB_HIP(ctx, hipStreamSynchronize(ctx->pair_down[k]));
+  }
   if (max_coef_bytes < ctx->max_coef) max_coef_bytes = ctx->max_coef;
   if (max_rgb_bytes < ctx->max_rgb) max_rgb_bytes = ctx->max_rgb;
   const int n = ctx->n_slots > 0 ? ctx->n_slots : ctx->n_slots_req;
@@ -429,13 +457,15 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   if (n_images > 1) {
     if (ctx->stream2 && (ctx->n_group_submits++ & 1u)) up = ctx->stream2;
     down = up;
-  }
-  // JPEGBLK_HOST_POOL=1 (A/B knob): every submission whole on one of the pool streams instead
-  static const bool host_pool = getenv("JPEGBLK_HOST_POOL") && getenv("JPEGBLK_HOST_POOL")[0] == '1';
-  if (host_pool) {
-    hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
-    if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-    up = down = ps;
+  } else if (ctx->stream2 && ctx->n_pairs > 1) {
+    // one image: the next of the K (upload + kernel, download) stream pairs
+    const int k = (int)(ctx->n_single_submits++ % (unsigned)ctx->n_pairs);
+    if (k > 0) {
+      if (!ctx->pair_up[k]) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pair_up[k], hipStreamNonBlocking));
+      if (!ctx->pair_down[k]) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pair_down[k], hipStreamNonBlocking));
+      up = ctx->pair_up[k];
+      down = ctx->pair_down[k];
+    }
   }
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, qtabs + (size_t)i * 256, s.h_q + (size_t)i * 192);

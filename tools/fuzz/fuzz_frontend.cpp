@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/jpegblk.h"
+#include "../../jpeg_decoder_amd/csrc/jb_huff.h"
 
 extern "C" long jw_encode_ex(const int16_t *coef, int width, int height, int hs, int vs, const uint16_t *qtabs,
                              const int *qtab_id, const uint8_t *dht, int restart_interval, int dqt16, int scan_mode,
@@ -117,6 +118,22 @@ static void mutate(std::vector<uint8_t> &d) {
   }
 }
 
+// The host half of the device-side entropy decoder (jb_huff_prepare_: header parse, table slots,
+// de-stuffing, interval table) on the same mutant: it must either refuse or produce a job whose
+// interval table is monotonic and inside the clean scan -- what the kernel relies on.
+static void prepare_once(const std::vector<uint8_t> &in) {
+  static JbHuffJob job;
+  if (jb_huff_prepare_(in.data(), in.size(), &job, nullptr) != JB_OK) return;
+  bool bad = job.starts.size() != (size_t)job.img.n_int + 1 || job.scan.size() < job.scan_len + 64 || job.starts.back() != job.scan_len ||
+             (uint64_t)job.img.n_int * job.img.ri < job.img.n_mcus || job.img.ny < 1 || job.img.ny > 4;
+  for (size_t i = 1; !bad && i < job.starts.size(); i++) bad = job.starts[i] < job.starts[i - 1];
+  for (int c = 0; !bad && c < 3; c++) bad = job.img.dc_slot[c] > 1 || job.img.ac_slot[c] > 1;
+  if (bad) {
+    fprintf(stderr, "jb_huff_prepare_ produced an inconsistent job\n");
+    abort();
+  }
+}
+
 int main(int argc, char **argv) {
   if (argc < 3) {
     fprintf(stderr, "usage: %s <seconds> <seed> [file.jpg ...]\n", argv[0]);
@@ -155,6 +172,7 @@ int main(int argc, char **argv) {
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < budget) {
     std::vector<uint8_t> d = seeds[rnd() % seeds.size()];
     mutate(d);
+    prepare_once(d);
     jb_image_desc desc;
     uint16_t q[256];
     int rc = jb_entropy_decode(d.data(), d.size(), &desc, q, nullptr, 0);
