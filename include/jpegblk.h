@@ -130,7 +130,8 @@ int jb_blocks_to_rgb(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef
 /* Asynchronous flavour over the staging ring, so the host Huffman stage of image i+1 overlaps
  * the device work of image i.  `coef`/`rgb` should come from jb_pinned_alloc for true overlap
  * and must stay valid until jb_wait(ticket) returns.  Blocks only when all slots are busy.
- * Submissions complete in order. */
+ * Submissions may complete out of order (small ones run on several stream pairs in turn): wait
+ * for the ticket, or jb_ctx_synchronize for everything. */
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef,
               const uint16_t *qtabs, uint8_t *rgb, int64_t rgb_stride, int *ticket);
 /* Several images of ONE geometry in one submission (one upload, one launch, one download): for

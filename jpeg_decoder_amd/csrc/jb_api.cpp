@@ -63,8 +63,13 @@ struct jb_ctx {
   // pairs used in turn -- pair 0 is (stream, stream2).  Within a pair the download of image i
   // overlaps the upload of image i + K (the link runs both ways); across pairs the chains of
   // different submitters do not queue behind each other.
+  // Measured with 16 submitting threads (profiles/r02b/ab_stream_pairs.txt): 1080p images (19 MB
+  // per submission) 1,951 images/s with one pair, 2,631 with eight; 8192x8192 images (402 MB) 164
+  // with one pair, 91 with eight -- several large copies in one direction at a time share the link
+  // badly -- so submissions of 64 MB or more all use pair 0.
   static constexpr int kMaxPairs = 8;
-  int n_pairs = 1;
+  static constexpr size_t kLargeSubmission = (size_t)64 << 20;
+  int n_pairs = 8;
   hipStream_t pair_up[kMaxPairs] = {}, pair_down[kMaxPairs] = {};
   unsigned n_single_submits = 0;
   unsigned n_group_submits = 0;
@@ -457,7 +462,7 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   if (n_images > 1) {
     if (ctx->stream2 && (ctx->n_group_submits++ & 1u)) up = ctx->stream2;
     down = up;
-  } else if (ctx->stream2 && ctx->n_pairs > 1) {
+  } else if (ctx->stream2 && ctx->n_pairs > 1 && coef_total + rgb_total < jb_ctx::kLargeSubmission) {
     // one image: the next of the K (upload + kernel, download) stream pairs
     const int k = (int)(ctx->n_single_submits++ % (unsigned)ctx->n_pairs);
     if (k > 0) {
