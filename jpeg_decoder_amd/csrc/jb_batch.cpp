@@ -224,6 +224,8 @@ struct Run {
   size_t dev_cap_coef, dev_cap_rgb;  // ring-slot capacity: bounds a group whose entropy stage runs on the device
   const char *const *paths;
   int n_paths, n_threads, inner_threads;
+  const std::vector<std::vector<int>> *lists;  // which files each host thread owns (indices into paths)
+  int n_dev_threads;                           // hybrid mode: threads 0 .. n_dev_threads-1 feed the device decoder
   uint8_t **rgb;
   int32_t *widths, *heights;
   int *statuses;
@@ -237,7 +239,7 @@ struct Run {
 void parse_pass(const Run &r, int t, std::vector<Parsed> &parsed, size_t *max_coef, size_t *max_rgb, double *t_read) {
   jb_bind_thread_near_device_(r.device);  // the file bytes are first touched here: keep them on the GPU's node
   for (size_t k = 0; k < parsed.size(); k++) {
-    const int i = t + (int)k * r.n_threads;
+    const int i = (*r.lists)[(size_t)t][k];
     Parsed &p = parsed[k];
     double a = now_s();
     if (!read_file(r.paths[i], p.bytes)) {
@@ -279,11 +281,14 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   // Files with restart intervals can have their entropy stage on the device; this thread then only
   // parses, removes the byte stuffing and packs.  Opt-in: JPEGBLK_GPU_HUFFMAN=1 (files with 16
   // intervals or more) or =2 (any file with DRI).  A group is all-device or all-host.
+  // =3: hybrid -- a quarter of the threads (at least one) feed the device decoder, which costs
+  // them almost no CPU, the others decode on the host: the two rates add up until the link is full.
   const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2');
+  const bool hybrid = knob && knob[0] == '3';
+  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2' || (hybrid && t < r.n_dev_threads));
   const uint32_t min_intervals = (knob && knob[0] == '2') ? 1u : 16u;
   std::vector<uint16_t> qtabs;
-  auto index_of = [&](int k) { return t + k * r.n_threads; };
+  auto index_of = [&](int k) { return (*r.lists)[(size_t)t][(size_t)k]; };
   auto report = [&](int i, int st, const std::string &text) {
     r.statuses[i] = st;
     if (st == JB_OK) return;
@@ -571,8 +576,33 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   Shared dev;
+  // Which files each thread owns.  Default: file i -> thread i % n_threads.  Hybrid mode
+  // (JPEGBLK_GPU_HUFFMAN=3): a quarter of the threads feed the device entropy decoder -- preparing
+  // an image costs them a twentieth of decoding it -- so they are dealt a larger share of the files
+  // (JPEGBLK_HYBRID_SHARE percent, default 60), the host-decoding threads the rest; the two rates
+  // add up until the link is full.
+  std::vector<std::vector<int>> lists((size_t)n_threads);
+  int n_dev_threads = 0;
+  {
+    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
+    if (knob && knob[0] == '3' && n_threads >= 2) {
+      n_dev_threads = (n_threads + 3) / 4;
+      const char *e = getenv("JPEGBLK_HYBRID_SHARE");
+      long share = e ? atol(e) : 60;
+      if (share < 1) share = 1;
+      if (share > 99) share = 99;
+      int nd = 0, nh = 0;
+      for (int i = 0; i < n_paths; i++) {
+        const bool to_dev = ((long)(i + 1) * share) / 100 > ((long)i * share) / 100;
+        if (to_dev) lists[(size_t)(nd++ % n_dev_threads)].push_back(i);
+        else lists[(size_t)(n_dev_threads + nh++ % (n_threads - n_dev_threads))].push_back(i);
+      }
+    } else {
+      for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
+    }
+  }
   Run r{d->device, 0, 0, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
-        rgb, widths, heights, statuses, d->arena, &dev, &tot};
+        &lists, n_dev_threads, rgb, widths, heights, statuses, d->arena, &dev, &tot};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
   // pass 1: headers, in parallel
@@ -582,7 +612,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   {
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; t++) {
-      parsed[(size_t)t].resize((size_t)((n_paths - t + n_threads - 1) / n_threads));
+      parsed[(size_t)t].resize(lists[(size_t)t].size());
       th.emplace_back([&, t] { parse_pass(r, t, parsed[(size_t)t], &mc[(size_t)t], &mr[(size_t)t], &tr[(size_t)t]); });
     }
     for (auto &x : th) x.join();
@@ -610,7 +640,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   size_t ring_bytes = 0;
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    if (knob && (knob[0] == '1' || knob[0] == '2')) {
+    if (knob && (knob[0] == '1' || knob[0] == '2' || knob[0] == '3')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
       const long mb = e ? atol(e) : 256;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
