@@ -225,7 +225,6 @@ struct Run {
   const char *const *paths;
   int n_paths, n_threads, inner_threads;
   const std::vector<std::vector<int>> *lists;  // which files each host thread owns (indices into paths)
-  int n_dev_threads;                           // hybrid mode: threads 0 .. n_dev_threads-1 feed the device decoder
   uint8_t **rgb;
   int32_t *widths, *heights;
   int *statuses;
@@ -281,11 +280,12 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   // Files with restart intervals can have their entropy stage on the device; this thread then only
   // parses, removes the byte stuffing and packs.  Opt-in: JPEGBLK_GPU_HUFFMAN=1 (files with 16
   // intervals or more) or =2 (any file with DRI).  A group is all-device or all-host.
-  // =3: hybrid -- a quarter of the threads (at least one) feed the device decoder, which costs
-  // them almost no CPU, the others decode on the host: the two rates add up until the link is full.
+  // (A hybrid -- a quarter of the threads feeding the device decoder with 60 % of the files, the rest
+  // decoding on the host -- was measured and is slower than either pure mode: 1,885 images/s against
+  // 2,681 host / 2,498 device on PIL 1080p files; large group downloads and many small uploads and
+  // downloads at once share the link badly.  Removed.)
   const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-  const bool hybrid = knob && knob[0] == '3';
-  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2' || (hybrid && t < r.n_dev_threads));
+  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2');
   const uint32_t min_intervals = (knob && knob[0] == '2') ? 1u : 16u;
   std::vector<uint16_t> qtabs;
   auto index_of = [&](int k) { return (*r.lists)[(size_t)t][(size_t)k]; };
@@ -576,33 +576,11 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   Shared dev;
-  // Which files each thread owns.  Default: file i -> thread i % n_threads.  Hybrid mode
-  // (JPEGBLK_GPU_HUFFMAN=3): a quarter of the threads feed the device entropy decoder -- preparing
-  // an image costs them a twentieth of decoding it -- so they are dealt a larger share of the files
-  // (JPEGBLK_HYBRID_SHARE percent, default 60), the host-decoding threads the rest; the two rates
-  // add up until the link is full.
+  // which files each thread owns: file i -> thread i % n_threads
   std::vector<std::vector<int>> lists((size_t)n_threads);
-  int n_dev_threads = 0;
-  {
-    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    if (knob && knob[0] == '3' && n_threads >= 2) {
-      n_dev_threads = (n_threads + 3) / 4;
-      const char *e = getenv("JPEGBLK_HYBRID_SHARE");
-      long share = e ? atol(e) : 60;
-      if (share < 1) share = 1;
-      if (share > 99) share = 99;
-      int nd = 0, nh = 0;
-      for (int i = 0; i < n_paths; i++) {
-        const bool to_dev = ((long)(i + 1) * share) / 100 > ((long)i * share) / 100;
-        if (to_dev) lists[(size_t)(nd++ % n_dev_threads)].push_back(i);
-        else lists[(size_t)(n_dev_threads + nh++ % (n_threads - n_dev_threads))].push_back(i);
-      }
-    } else {
-      for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
-    }
-  }
+  for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
   Run r{d->device, 0, 0, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
-        &lists, n_dev_threads, rgb, widths, heights, statuses, d->arena, &dev, &tot};
+        &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
   // pass 1: headers, in parallel
@@ -640,7 +618,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   size_t ring_bytes = 0;
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    if (knob && (knob[0] == '1' || knob[0] == '2' || knob[0] == '3')) {
+    if (knob && (knob[0] == '1' || knob[0] == '2')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
       const long mb = e ? atol(e) : 256;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;

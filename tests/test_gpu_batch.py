@@ -58,7 +58,7 @@ def files_8192(tmp_path_factory, oracle):
     return _write_files(d, "c5", 8192, 8192, 2, 2, 4, 1, 512, oracle)  # DRI = one MCU row
 
 
-@pytest.mark.parametrize("entropy", ["host", "device", "hybrid"])
+@pytest.mark.parametrize("entropy", ["host", "device"])
 @pytest.mark.parametrize("devices", [None, [0, 0]])
 @pytest.mark.parametrize("arena", [False, True])
 def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices, entropy):
@@ -69,8 +69,8 @@ def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, de
     total = sum((w.size + 255) // 256 * 256 for w in want)
     if entropy == "host":
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
-    else:  # hybrid (=3): a quarter of the threads feed the device decoder with 60 % of the files
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1" if entropy == "device" else "3")
+    else:
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     for group_mb in (None, "0"):
         if group_mb is None:
             monkeypatch.delenv("JPEGBLK_GROUP_MB", raising=False)
@@ -80,8 +80,7 @@ def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, de
             for _ in range(2):  # second run: buffers, ring and arena are reused
                 imgs, st, tm = dec.run(paths)
                 _check(imgs, st, tm, want)
-            n_dev = dec.device_entropy_images
-            assert n_dev == (2 * len(paths) if entropy == "device" else 0) or (entropy == "hybrid" and 0 < n_dev < 2 * len(paths))
+            assert dec.device_entropy_images == (2 * len(paths) if entropy == "device" else 0)
 
 
 @pytest.mark.parametrize("entropy", ["host", "device"])
