@@ -15,14 +15,14 @@
 // Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
 //   LDS: the image's table set (18 KiB: an 11-bit code table per AC / DC slot + canonical arrays for
 //   longer codes) + a 64-byte ring of upcoming stream bytes per lane (16 KiB): four workgroups per CU.
-//   The (MCU, block-in-MCU) loops are wave-uniform -- every interval holds the same number of MCUs
-//   but the image's last -- so the component, and with it the table, is uniform per iteration; only
-//   the symbol loop inside a block diverges.  The host zeroes the coefficient area (one memset per
-//   submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
+//   Every lane walks its own interval as a state machine, one symbol per step (DC and AC symbols
+//   are the same step); lanes are not held together at block boundaries, so a wave takes as many
+//   steps as its longest interval has symbols.  The host zeroes the coefficient area (one memset
+//   per submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
 //   into its block's 128-byte line -- the layout is the fused pixel kernel's input.
 //   The bit stream is read through a 3-dword register window per lane (two dwords in use, one
-//   ahead) fed from the lane's LDS ring, which is topped up from HBM at block boundaries (struct
-//   Stream); a lookup consumes at most 27 bits, so the window advances by at most one dword per step.
+//   ahead) fed from the lane's LDS ring, which is topped up from HBM every 4 steps (struct Stream);
+//   a symbol consumes at most 27 bits, so the window advances by at most one dword per step.
 // Safety: every stream read is clamped into the image's padded scan; k only grows inside a block
 // (at most 63 iterations); output indices come from host-validated counts.  Corrupt data sets the
 // image's status word and the host re-decodes that image with the serial reader for the precise
@@ -40,9 +40,9 @@ constexpr uint32_t kRing = 64;   // bytes of the stream a lane keeps staged in L
 
 // A lane's view of its interval's bit stream.  Bits are taken from a two-dword register window
 // (d0:d1 at bit offset `off`, d2 one dword ahead); the dwords come from a 128-byte ring in LDS that
-// is topped up from HBM in aligned 16-byte chunks at BLOCK boundaries -- a wave-uniform point, and
-// the chunk asked for at one boundary is written into the ring at the next, so its latency is
-// hidden behind a whole block's decoding.  (Fetching per dword from HBM instead put a memory round
+// is topped up from HBM in aligned 16-byte chunks every 4 steps -- a wave-uniform point, and the
+// chunk asked for at one such point is written into the ring at the next, so its latency is hidden
+// behind four steps of decoding.  (Fetching per dword from HBM instead put a memory round
 // trip into every iteration of the symbol loop: with 64 lanes in flight some lane crosses a dword
 // in every iteration, and the wave waits for it.)  A block that outruns the ring reads straight
 // from HBM, which is only slower.
@@ -219,56 +219,65 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
   int pred0 = 0, pred1 = 0, pred2 = 0;
   uint32_t err = 0;
 
-  for (uint32_t mi = 0; mi < img.ri; mi++) {
-    if (__builtin_amdgcn_ballot_w64(mi < count) == 0) break;  // wave-uniform: no lane of this wave has MCUs left
-    for (uint32_t b = 0; b < nb; b++) {
-      const int c = b < img.ny ? 0 : (int)(b - img.ny) + 1;  // wave-uniform
-      const int dcs = (int)((slots >> c) & 1u), acs = (int)((slots >> (4 + c)) & 1u);
-      if (mi < count) {
+  // ---- one symbol per step, every lane at its own place in its own interval -------------------
+  // What reference decodeMCUComponent does per block (jpeg.cpp:322-403; same results as the host
+  // decoder's decode_block_clean) as a per-lane state machine: k == 0 means "the DC symbol is next",
+  // 1..63 "an AC symbol for zig-zag position k is next".  Lanes are NOT held together at block
+  // boundaries: a wave then takes as many steps as its longest INTERVAL has symbols (sums of 720
+  // blocks barely differ between lanes), not the sum over block rounds of the longest BLOCK of the
+  // round (a block of 35 symbols among 64 lanes in most rounds, against 11 on average) -- a third
+  // of the steps on a photographic file.  DC and AC symbols are the same step: code from the 11-bit
+  // window table of the lane's current component and kind, magnitude bits out of the same 32-bit
+  // window, one consume, one predicated store.  The ring is topped up every 4 steps, a wave-uniform
+  // point: a lane consumes at most 14 bytes in 4 steps, a top-up asks for up to 32 as soon as fewer
+  // than 37 lie ahead, and what it asks for arrives at the next one -- the ring never runs dry.
+  bool live = active && count > 0;
+  uint32_t blk = 0, mcus_left = count;
+  int k = 0;
+  for (uint32_t step = 0;; step++) {
+    if ((step & 3u) == 0) {
+      if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // wave-uniform: every lane of this wave is through
 #ifndef JBH_NO_TOPUP
-        s.top_up();
+      if (live) s.top_up();
 #endif
-        // ---- one block: what reference decodeMCUComponent does (jpeg.cpp:322-403), same results as
-        // the host decoder's decode_block_clean.  Every symbol is ONE step of the same shape -- code
-        // from the 11-bit window table, magnitude bits out of the same 32-bit window, one consume,
-        // one predicated store -- so the lanes of a wave differ in how many steps they take, not
-        // in which path they are on.
-        int diff = 0;
-        {
-          const uint32_t bits = s.window();
-          uint32_t t = lds.t.dcl[dcs][bits >> 21];
-          if (t == 0) t = long_code(bits, lds.t, dcs);
-          const uint32_t len = t >> 8, sz = t & 0xffu;
-          if (t == 0 || sz > 11) {
-            err |= 1;
-          } else {
-            if (sz) diff = extend((bits << len) >> (32 - sz), (int)sz);  // len + sz <= 27 bits of the 32
-            s.consume(len + sz);
-          }
-        }
-        int pred = (c == 0 ? pred0 : c == 1 ? pred1 : pred2) + diff;
-        if (pred < -32768 || pred > 32767) err |= 1, pred = 0;
-        if (c == 0) pred0 = pred;
-        else if (c == 1) pred1 = pred;
-        else pred2 = pred;
-        if (pred) JBH_STORE(out[0], (int16_t)pred);
-        int k = 1;
-        bool done = false;
-        while (!done) {
-          const uint32_t bits = s.window();
-          uint32_t t = lds.t.acl[acs][bits >> 21];
-          if (t == 0) t = long_code(bits, lds.t, 2 + acs);
-          const uint32_t len = t >> 8, rs = t & 0xffu, sz = rs & 15u;
-          const bool eob = rs == 0;
-          k += rs == 0xf0u ? 16 : (int)(rs >> 4);  // (a ZRL, or the run of a run/size symbol; 0 for EOB)
-          const bool bad = t == 0 || (!eob && (k > 63 || sz > 10));  // reference jpeg.cpp:372-385
-          if (sz && !bad) JBH_STORE(out[zz[k & 63]], (int16_t)extend((bits << len) >> (32 - sz), (int)sz));
-          k += sz ? 1 : 0;
-          if (!bad) s.consume(len + sz);  // <= 16 + 10 bits of the 32
-          err |= bad ? 1u : 0u;
-          done = eob || bad || k > 63;
-        }
+    }
+    if (live) {
+      const int c = blk < img.ny ? 0 : (int)(blk - img.ny) + 1;
+      const bool isdc = k == 0;
+      const uint32_t slot = (slots >> (isdc ? c : 4 + c)) & 1u;
+      const uint32_t bits = s.window();
+      // acl[2][2048] and dcl[2][2048] lie back to back: one 16-bit read at a per-lane offset
+      uint32_t t = ((const uint16_t *)lds.t.acl)[(isdc ? 4096u : 0u) + slot * 2048u + (bits >> 21)];
+      if (t == 0) t = long_code(bits, lds.t, (int)((isdc ? 0u : 2u) + slot));
+      const uint32_t len = t >> 8, rs = t & 0xffu;
+      const uint32_t sz = isdc ? rs : (rs & 15u);
+      const bool eob = !isdc && rs == 0;
+      const int kk = k + (isdc ? 0 : rs == 0xf0u ? 16 : (int)(rs >> 4));  // (a ZRL, or the run of a run/size symbol)
+      bool bad = t == 0 || (isdc ? sz > 11 : (!eob && (kk > 63 || sz > 10)));  // reference jpeg.cpp:372-385
+      int val = 0;
+      if (sz && !bad) val = extend((bits << len) >> (32 - sz), (int)sz);  // len + sz <= 27 bits of the 32
+      if (isdc) {
+        int pr = (c == 0 ? pred0 : c == 1 ? pred1 : pred2) + val;
+        if (pr < -32768 || pr > 32767) bad = true, pr = 0;
+        if (c == 0) pred0 = pr;
+        else if (c == 1) pred1 = pr;
+        else pred2 = pr;
+        val = pr;
+      }
+      if (!bad && (isdc ? val != 0 : sz != 0)) JBH_STORE(out[zz[kk & 63]], (int16_t)val);
+      if (!bad) s.consume(len + sz);
+      k = isdc ? 1 : eob ? 64 : kk + (sz ? 1 : 0);
+      if (bad) {
+        err |= 1;
+        live = false;  // what follows in this interval is garbage; the host re-decodes the image
+      }
+      if (k > 63) {  // the block is complete: on to the next one of this lane's interval
+        k = 0;
         out += 64;
+        if (++blk == nb) {
+          blk = 0;
+          if (--mcus_left == 0) live = false;
+        }
       }
     }
   }
