@@ -370,8 +370,8 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   // Files with restart intervals can have their entropy stage on the device too (jb_huff.hip): the
   // host then only parses the headers and removes the byte stuffing.  Opt-in -- JPEGBLK_GPU_HUFFMAN=1
   // (16 intervals or more) or =2 (any number) -- because one image is at most a few hundred lanes
-  // of serial work: the device decoder wins on batches, not on a single image's latency
-  // (DESIGN.md section 9).  Whatever the device decoder does not take or flags as corrupt goes
+  // of serial work: the device decoder wins on batches (jb_batch_decoder), not on a single
+  // image's latency.  Whatever the device decoder does not take or flags as corrupt goes
   // through the host decoder below, which gives the precise answer.
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
