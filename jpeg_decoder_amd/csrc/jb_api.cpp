@@ -26,6 +26,19 @@
 
 namespace {
 
+// The staging ring drives up to 8 stream pairs and 16 pool streams per context; the HIP runtime
+// maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue
+// run their kernels one after the other.  Measured with 16 submitting threads: 1,024 1080p files
+// 2,838 -> 3,211 images/s (host entropy), 4,807 -> 5,428 (device entropy), 128 files 2,398 -> 3,344,
+// with 16 queues instead of 4.  So the library asks for 16 when it is loaded -- only if the variable
+// is not set already, and only effective if the process has not initialised HIP yet
+// (JPEGBLK_HW_QUEUES=0 leaves the runtime's default alone, =N asks for N).
+__attribute__((constructor)) void jb_ask_for_hw_queues() {
+  const char *k = getenv("JPEGBLK_HW_QUEUES");
+  if (k && k[0] == '0' && k[1] == 0) return;
+  setenv("GPU_MAX_HW_QUEUES", (k && k[0]) ? k : "16", 0);
+}
+
 thread_local std::string g_tls_error = "";
 
 struct Slot {
