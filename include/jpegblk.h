@@ -175,7 +175,10 @@ typedef struct jb_device_batch {
   int64_t qtab_image_stride; /* bytes between images' [3][64] tables; 0 = shared */
   uint8_t *d_rgb;
   int64_t rgb_image_stride; /* bytes between images */
-  int64_t rgb_row_stride;   /* bytes between pixel rows, >= 3*width */
+  int64_t rgb_row_stride;   /* bytes between pixel rows, >= 3*width; any value works (lanes store 12 bytes
+                             * at byte-aligned addresses), multiples of 64 are fastest: on small images
+                             * a tightly packed odd stride costs about ten points of roofline (partial
+                             * lines at the ends of every 768-byte wave store) */
 } jb_device_batch;
 
 int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *batch, void *stream);
