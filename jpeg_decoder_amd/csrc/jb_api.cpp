@@ -529,10 +529,10 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // upload a packed submission (jb_huff_pack_) and launch the decoder: image i's coefficient blocks
 // land at d_out + i * coef_stride bytes, its status word at s.d_status[i]
 int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up) {
-  if (lay.total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
+  if (lay.device_total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
     if (s.d_blob) (void)hipFree(s.d_blob);
     s.d_blob = nullptr, s.blob_cap = 0;
-    const size_t cap = lay.total + lay.total / 4 + 65536;
+    const size_t cap = lay.device_total + lay.device_total / 4 + 65536;
     JB_HIP(ctx, hipMalloc(&s.d_blob, cap));
     s.blob_cap = cap;
   }
@@ -554,6 +554,13 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.coef = d_out;
   p.status = s.d_status;
   p.n_wgs = (int32_t)lay.n_wg;
+  p.sync_wgs = (const JbHuffWg *)(d + lay.off_sync_wg);
+  p.n_sync_wgs = (int32_t)lay.n_sync_wg;
+  p.n_sync_images = (int32_t)lay.n_sync_images;
+  p.sync_images = (const uint32_t *)(d + lay.off_sync_img);
+  p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
+  p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
+  p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
 }
@@ -911,14 +918,18 @@ size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n) {
     n_starts += jobs[i]->starts.size();
     scan_bytes += ((jobs[i]->scan.size() + 15) & ~(size_t)15);
   }
-  return (size_t)n * sizeof(JbHuffImage) + n_wg * sizeof(JbHuffWg) + (size_t)n * sizeof(JbHuffTables) + n_starts * 4 + scan_bytes + 64;
+  // (the self-synchronising decoder's lists: a workgroup per kJbHuffLanes chunks, an index per image)
+  size_t n_sync_wg = 0;
+  for (int i = 0; i < n; i++) n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+  return (size_t)n * sizeof(JbHuffImage) + (n_wg + n_sync_wg) * sizeof(JbHuffWg) + (size_t)n * (sizeof(JbHuffTables) + 4) + n_starts * 4 +
+         scan_bytes + 128;
 }
 
 int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint8_t *h, JbHuffLayout *lay) {
   auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   std::vector<int> set_of((size_t)n, 0);
   std::vector<int> sets;  // index of the first job that owns each distinct table set
-  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
+  size_t n_wg = 0, n_starts = 0, scan_bytes = 0, n_sync_wg = 0, n_sync_images = 0, n_chunks = 0;
   for (int i = 0; i < n; i++) {
     int found = -1;
     for (size_t k = 0; k < sets.size() && found < 0; k++)
@@ -928,7 +939,12 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
       sets.push_back(i);
     }
     set_of[(size_t)i] = found;
-    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    if (jobs[i]->img.n_chunks == 0) n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    else {
+      n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+      n_sync_images++;
+      n_chunks += jobs[i]->img.n_chunks;
+    }
     n_starts += jobs[i]->starts.size();
     scan_bytes += a16(jobs[i]->scan.size());
     if (n > 1 && (int64_t)jobs[i]->geo.coef_bytes > coef_stride) return JB_ERR_CAPACITY;
@@ -937,16 +953,27 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   lay->off_wg = a16((size_t)n * sizeof(JbHuffImage));
   lay->off_tab = a16(lay->off_wg + n_wg * sizeof(JbHuffWg));
   lay->off_starts = lay->off_tab + sets.size() * sizeof(JbHuffTables);
-  lay->off_scan = a16(lay->off_starts + n_starts * 4);
+  lay->off_sync_wg = a16(lay->off_starts + n_starts * 4);
+  lay->off_sync_img = a16(lay->off_sync_wg + n_sync_wg * sizeof(JbHuffWg));
+  lay->off_scan = a16(lay->off_sync_img + n_sync_images * 4);
   lay->total = lay->off_scan + scan_bytes;
+  // device-only scratch behind the uploaded bytes
+  lay->off_state_a = a16(lay->total);
+  lay->off_state_b = a16(lay->off_state_a + n_chunks * sizeof(JbChunkState));
+  lay->off_base = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
+  lay->device_total = a16(lay->off_base + n_chunks * 4);
   lay->n = n;
   lay->n_wg = (int)n_wg;
+  lay->n_sync_wg = (int)n_sync_wg;
+  lay->n_sync_images = (int)n_sync_images;
   lay->coef_stride = coef_stride;
-  if (lay->total > 0xffffff00u || n_wg > 0x7fffffffu) return JB_ERR_CAPACITY;
+  if (lay->device_total > 0xffffff00u || n_wg > 0x7fffffffu || n_sync_wg > 0x7fffffffu) return JB_ERR_CAPACITY;
   JbHuffImage *im = (JbHuffImage *)(h + lay->off_img);
   JbHuffWg *wg = (JbHuffWg *)(h + lay->off_wg);
+  JbHuffWg *swg = (JbHuffWg *)(h + lay->off_sync_wg);
+  uint32_t *simg = (uint32_t *)(h + lay->off_sync_img);
   uint32_t *st = (uint32_t *)(h + lay->off_starts);
-  size_t w = 0, si = 0, sc = lay->off_scan;
+  size_t w = 0, si = 0, sc = lay->off_scan, sw = 0, sn = 0, chunk0 = 0;
   for (size_t k = 0; k < sets.size(); k++) memcpy(h + lay->off_tab + k * sizeof(JbHuffTables), &jobs[sets[k]]->tables, sizeof(JbHuffTables));
   for (int i = 0; i < n; i++) {
     const JbHuffJob &j = *jobs[i];
@@ -955,7 +982,14 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
     im[i].int_off = (uint32_t)si;
     im[i].table_set = (uint32_t)set_of[(size_t)i];
     im[i].coef_off = (int64_t)i * coef_stride;
-    for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
+    if (j.img.n_chunks == 0) {
+      for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
+    } else {
+      im[i].state_off = (uint32_t)chunk0;
+      chunk0 += j.img.n_chunks;
+      simg[sn++] = (uint32_t)i;
+      for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) swg[sw++] = JbHuffWg{(uint32_t)i, f};
+    }
     memcpy(st + si, j.starts.data(), j.starts.size() * 4);
     si += j.starts.size();
     memcpy(h + sc, j.scan.data(), j.scan.size());

@@ -394,7 +394,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       bool eligible = false;
       if (dev_entropy) {
         job.reset(new JbHuffJob());
-        eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr) == JB_OK && job->img.n_int >= min_intervals;
+        eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_intervals);
       }
       if (n == 0) on_device = eligible;
       else if (eligible != on_device) break;  // the next group starts with this image

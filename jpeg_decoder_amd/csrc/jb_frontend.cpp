@@ -274,9 +274,10 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   rc = jb_geometry_of(&fr->desc, &job->geo);
   if (rc != JB_OK) return done(rc, "bad frame geometry");
   const int64_t n_mcus = (int64_t)job->geo.mcus_x * job->geo.mcus_y;
-  const int ri = fr->restart_interval;
-  if (ri <= 0) return done(JB_ERR_UNSUPPORTED, "no restart intervals: host decoder");
-  const int64_t n_int = (n_mcus + ri - 1) / ri;
+  // with restart intervals: one lane per interval; without: the self-synchronising decoder, one
+  // lane per 256-byte chunk of the scan (jb_huff.hip)
+  const int ri = fr->restart_interval > 0 ? fr->restart_interval : 0;
+  const int64_t n_int = ri > 0 ? (n_mcus + ri - 1) / ri : 1;
   // table slots: the three components may name at most two DC and two AC tables
   int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
   for (int c = 0; c < 3; c++) {
@@ -311,7 +312,7 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   CleanScan &cs = tls_scan;
   unstuff(fr->scan, fr->scan + fr->scan_len, cs);
   if ((int64_t)cs.n_intervals() != n_int) return done(JB_ERR_UNSUPPORTED, "restart markers do not match the frame: host decoder");
-  if (cs.start.back() > 0xfffff000u) return done(JB_ERR_UNSUPPORTED, "scan too large for 32-bit offsets: host decoder");
+  if (cs.start.back() > 0x0ffff000u) return done(JB_ERR_UNSUPPORTED, "scan too large for 32-bit bit offsets: host decoder");
   job->scan_len = cs.start.back();
   job->scan.assign(cs.bytes.begin(), cs.bytes.begin() + (long)(job->scan_len + 64));  // (unstuff zero-pads far beyond 64)
   job->starts.resize(cs.start.size());
@@ -319,10 +320,14 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   job->img.scan_off = job->img.int_off = job->img.table_set = 0;
   job->img.scan_len = (uint32_t)job->scan_len;
   job->img.n_int = (uint32_t)n_int;
-  job->img.ri = (uint32_t)ri;
+  job->img.ri = (uint32_t)(ri > 0 ? ri : n_mcus);
   job->img.n_mcus = (uint32_t)n_mcus;
   job->img.ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
   job->img.coef_off = 0;
+  job->img.n_blocks = (uint32_t)(n_mcus * (job->img.ny + 2));
+  job->img.n_chunks = ri > 0 ? 0u : (uint32_t)((job->scan_len + kJbChunkBytes - 1) / kJbChunkBytes);
+  job->img.state_off = job->img.reserved = 0;
+  if (ri == 0 && job->img.n_chunks == 0) return done(JB_ERR_FORMAT, "empty scan");
   return done(JB_OK, "");
 }
 
@@ -378,7 +383,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
     const uint32_t min_int = (knob && knob[0] == '2') ? 1u : 16u;
     if (knob && (knob[0] == '1' || knob[0] == '2')) {
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
-      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && job->img.n_int >= min_int) {
+      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int)) {
         uint8_t *out = (uint8_t *)malloc((size_t)job->geo.rgb_bytes);
         if (!out) return jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
         const int rc = jb_decode_job_(ctx, job.get(), out, 3LL * job->desc.width);

@@ -32,11 +32,25 @@ struct JbHuffImage {
   int64_t coef_off;    // byte offset of the image's coefficient blocks in the output
   uint8_t dc_slot[4];  // table slot (0 / 1) of Y, Cb, Cr
   uint8_t ac_slot[4];
+  // scans WITHOUT restart intervals (n_int == 1): the self-synchronising decoder works on chunks
+  uint32_t n_chunks;   // kJbChunkBytes-byte chunks of the clean scan (0 = the interval decoder is used)
+  uint32_t state_off;  // index of the image's first entry in the chunk state / base arrays
+  uint32_t n_blocks;   // coded blocks in the image: n_mcus * (ny + 2)
+  uint32_t reserved;
 };
 
 struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart intervals of one image
   uint32_t image;
   uint32_t first_interval;
+};
+
+constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder
+constexpr int kJbSyncRounds = 8;         // synchronisation passes before the writing pass (which verifies)
+
+// Exit state of a chunk's decode: where the first symbol of the next chunk starts and in which state
+struct JbChunkState {
+  uint32_t bitpos;  // bit position in the clean scan
+  uint32_t meta;    // k (0 = a DC symbol is next, else zig-zag position) | block-in-MCU << 8 | blocks completed in the chunk << 16
 };
 
 struct JbHuffLaunch {
@@ -46,8 +60,15 @@ struct JbHuffLaunch {
   const JbHuffImage *images;   // device
   const JbHuffWg *wgs;         // device
   int16_t *coef;               // device: output, decode-order int16 blocks (include/jpegblk.h)
-  uint32_t *status;            // device: one word per image, non-zero = corrupt data met (bit 0) / overrun (bit 1)
+  uint32_t *status;            // device: one word per image: bit 0 corrupt data, bit 1 overrun, bit 2 the chunks did not synchronise
   int32_t n_wgs;
+  // the self-synchronising decoder (images with n_chunks > 0): its own workgroup list and scratch
+  const JbHuffWg *sync_wgs;    // device: one workgroup = up to kJbHuffLanes consecutive chunks of one image
+  int32_t n_sync_wgs;
+  int32_t n_sync_images;       // images with n_chunks > 0 ...
+  const uint32_t *sync_images; // ... and their indices (device)
+  JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each
+  uint32_t *base;              // device scratch: index of the block a chunk starts in
 };
 
 constexpr int kJbHuffLanes = 256;  // restart intervals per workgroup (LDS: 18 KiB of tables + a 64-byte stream ring per lane)
@@ -84,7 +105,16 @@ struct JbHuffLayout {
   size_t off_img = 0, off_wg = 0, off_tab = 0, off_starts = 0, off_scan = 0, total = 0;
   int n = 0, n_wg = 0;
   int64_t coef_stride = 0;
+  // the self-synchronising decoder's part: its workgroup list and image list (uploaded), and the
+  // device-only scratch behind the uploaded bytes (chunk states x 2, chunk bases)
+  size_t off_sync_wg = 0, off_sync_img = 0, off_state_a = 0, off_state_b = 0, off_base = 0, device_total = 0;
+  int n_sync_wg = 0, n_sync_images = 0;
 };
+// Is the device decoder worth taking for this image?  Restart-interval mode: at least `min_intervals`
+// intervals; self-synchronising mode (no DRI): at least 16 chunks.
+inline bool jb_huff_worth_it_(const JbHuffJob &job, uint32_t min_intervals) {
+  return job.img.n_chunks > 0 ? job.img.n_chunks >= 16u : job.img.n_int >= min_intervals;
+}
 // Upper bound of the blob size for these jobs; and the packing itself (pure host code, no HIP: the
 // batch decoder's threads pack into their own pinned buffers WITHOUT holding the shared context's
 // lock -- twelve megabytes of memcpy per group under that lock serialised the whole decoder).

@@ -288,9 +288,291 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
   }
 }
 
+// ================================================================================================
+// Scans WITHOUT restart intervals: the self-synchronising decoder.
+//
+// A Huffman stream can only be decoded from its start -- but a decoder started at a wrong place,
+// in a wrong state, falls into step with the true symbol sequence after a few symbols or blocks
+// and stays in step from then on.  So the clean scan is cut into chunks of kJbChunkBytes bytes, one
+// lane per chunk:
+//   sync pass 0      every lane decodes its chunk from the chunk's first bit, assuming "a DC symbol
+//                    of the MCU's first block is next", and records its EXIT state: the bit at
+//                    which the first symbol of the next chunk starts, the position k inside the
+//                    block, the block's place in the MCU, and how many blocks it completed;
+//   sync pass r > 0  every lane decodes its chunk again, now from the exit state its left neighbour
+//                    recorded in pass r - 1 (lane 0: from the true start).  Correct states spread
+//                    from the left, at least one chunk per pass, in practice across the whole scan
+//                    in two or three passes because most lanes had fallen into step inside their
+//                    own chunk already;
+//   scan             exclusive prefix sum of the blocks completed per chunk: the block each chunk starts in;
+//   write pass       every lane decodes its chunk once more from its neighbour's final exit state
+//                    and this time stores the coefficients (DC as differences) -- and VERIFIES that
+//                    it ends in the exit state recorded for it: if every lane does, the chain from the
+//                    true start is consistent, i.e. this is the one true decode; if not (not yet
+//                    synchronised after kJbSyncRounds passes, or corrupt data) the image's status
+//                    word is set and the host decodes that image;
+//   DC pass          per component, the running sum of the DC differences (T.81 F.2.1.3.1; reference
+//                    jpeg.cpp:335-345) over the component's blocks in decode order.
+// A step is the same as in the interval decoder above; the tables, the stream ring and the layout
+// of the output are shared.  (Idea: Klein & Wiseman 2003; Weissenberger & Schmidt 2018 for JPEG on GPUs.)
+
+namespace {
+
+struct ChunkLane {
+  uint32_t k, blk, nblk;  // position in the block (0 = DC next), block within the MCU, blocks completed
+};
+
+// one symbol; stores == false: only the state moves.  Returns false when the data cannot be what
+// the state says (the caller decides what that means).
+template <bool kStore>
+__device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, const uint8_t *zz, uint32_t slots, uint32_t ny, uint32_t nb,
+                                           ChunkLane &st, int16_t *block_out) {
+  const int c = st.blk < ny ? 0 : (int)(st.blk - ny) + 1;
+  const bool isdc = st.k == 0;
+  const uint32_t slot = (slots >> (isdc ? c : 4 + c)) & 1u;
+  const uint32_t bits = s.window();
+  uint32_t e = ((const uint16_t *)t.acl)[(isdc ? 4096u : 0u) + slot * 2048u + (bits >> 21)];
+  if (e == 0) e = long_code(bits, t, (int)((isdc ? 0u : 2u) + slot));
+  const uint32_t len = e >> 8, rs = e & 0xffu;
+  const uint32_t sz = isdc ? rs : (rs & 15u);
+  const bool eob = !isdc && rs == 0;
+  const uint32_t kk = st.k + (isdc ? 0u : rs == 0xf0u ? 16u : (rs >> 4));
+  if (e == 0 || (isdc ? sz > 11 : (!eob && (kk > 63 || sz > 10)))) return false;
+  if (kStore && sz) {
+    const int val = extend((bits << len) >> (32 - sz), (int)sz);  // (a DC symbol: the difference; the DC pass sums them)
+    JBH_STORE(block_out[zz[kk & 63]], (int16_t)val);
+  }
+  s.consume(len + sz);
+  st.k = isdc ? 1u : eob ? 64u : kk + (sz ? 1u : 0u);
+  if (st.k > 63) {
+    st.k = 0;
+    st.nblk++;
+    if (++st.blk == nb) st.blk = 0;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void open_at_bit(Stream &s, uint32_t bit) {
+  s.open(bit >> 3);
+  s.off += bit & 7u;  // (start & 3) * 8 + (bit & 7) <= 31
+}
+
+}  // namespace
+
+// one synchronisation pass (round 0: from the chunk starts; later rounds: from the left neighbour's exit state)
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuffLaunch p, const int round, const JbChunkState *src, JbChunkState *dst) {
+  __shared__ __attribute__((aligned(16))) LdsTables lds;
+  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
+  __shared__ uint8_t zz[64];
+  const int tid = threadIdx.x;
+  const JbHuffWg wg = p.sync_wgs[blockIdx.x];
+  const JbHuffImage img = p.images[wg.image];
+  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
+                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
+  {
+    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
+    uint4 *dst4 = (uint4 *)&lds.t;
+    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
+    if (tid < 64) zz[tid] = kZigZagDev[tid];
+  }
+  __syncthreads();
+  const uint32_t ci = wg.first_interval + (uint32_t)tid;  // this lane's chunk
+  const bool active = ci < img.n_chunks;
+  const uint32_t nb = img.ny + 2;
+  const uint32_t total_bits = img.scan_len * 8u;
+  uint32_t bit = 0;
+  ChunkLane st{0, 0, 0};
+  if (active && ci > 0) {
+    if (round == 0) {
+      bit = ci * (kJbChunkBytes * 8u);
+    } else {
+      const JbChunkState prev = src[img.state_off + ci - 1];
+      bit = prev.bitpos;
+      st.k = prev.meta & 0xffu;
+      st.blk = (prev.meta >> 8) & 0xffu;
+    }
+  }
+  uint32_t end_bit = (ci + 1) * (kJbChunkBytes * 8u);
+  if (end_bit > total_bits) end_bit = total_bits;
+  if (bit > total_bits) bit = total_bits;
+  Stream s;
+  s.base = p.scan + img.scan_off;
+  s.limit = (img.scan_len + 48u) & ~15u;
+  s.ring = rings + tid * kRing;
+  open_at_bit(s, active ? bit : 0u);
+  bool live = active && bit < end_bit;
+  for (uint32_t step = 0;; step++) {
+    if ((step & 3u) == 0) {
+      if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+      if (live) s.top_up();
+    }
+    if (live) {
+      if (!chunk_step<false>(s, lds.t, zz, slots, img.ny, nb, st, nullptr)) {
+        // not a possible continuation of this state: the lane is out of step (or the data is corrupt,
+        // which the write pass will report) -- move on by one bit and expect a block to start
+        s.consume(1);
+        st.k = 0;
+      }
+      live = (uint32_t)s.bitpos() < end_bit;
+    }
+  }
+  if (active) dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
+}
+
+// exclusive prefix sum of the blocks completed per chunk: one workgroup per image
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_scan_kernel(const JbHuffLaunch p, const JbChunkState *fin) {
+  __shared__ uint32_t part[kJbHuffLanes];
+  const JbHuffImage img = p.images[p.sync_images[blockIdx.x]];
+  const uint32_t n = img.n_chunks, per = (n + kJbHuffLanes - 1) / kJbHuffLanes;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += fin[img.state_off + i].meta >> 16;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < kJbHuffLanes; i++) {
+      const uint32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t i = lo; i < hi; i++) {
+    p.base[img.state_off + i] = run;
+    run += fin[img.state_off + i].meta >> 16;
+  }
+}
+
+// the writing pass: decode from the left neighbour's final exit state, store, verify
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuffLaunch p, const JbChunkState *fin) {
+  __shared__ __attribute__((aligned(16))) LdsTables lds;
+  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
+  __shared__ uint8_t zz[64];
+  const int tid = threadIdx.x;
+  const JbHuffWg wg = p.sync_wgs[blockIdx.x];
+  const JbHuffImage img = p.images[wg.image];
+  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
+                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
+  {
+    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
+    uint4 *dst4 = (uint4 *)&lds.t;
+    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
+    if (tid < 64) zz[tid] = kZigZagDev[tid];
+  }
+  __syncthreads();
+  const uint32_t ci = wg.first_interval + (uint32_t)tid;
+  const bool active = ci < img.n_chunks;
+  const uint32_t nb = img.ny + 2;
+  const uint32_t total_bits = img.scan_len * 8u;
+  uint32_t bit = 0, block = 0;
+  ChunkLane st{0, 0, 0};
+  JbChunkState want{0, 0};
+  if (active) {
+    want = fin[img.state_off + ci];
+    block = p.base[img.state_off + ci];
+    if (ci > 0) {
+      const JbChunkState prev = fin[img.state_off + ci - 1];
+      bit = prev.bitpos;
+      st.k = prev.meta & 0xffu;
+      st.blk = (prev.meta >> 8) & 0xffu;
+    }
+  }
+  uint32_t end_bit = (ci + 1) * (kJbChunkBytes * 8u);
+  if (end_bit > total_bits) end_bit = total_bits;
+  if (bit > total_bits) bit = total_bits;
+  Stream s;
+  s.base = p.scan + img.scan_off;
+  s.limit = (img.scan_len + 48u) & ~15u;
+  s.ring = rings + tid * kRing;
+  open_at_bit(s, active ? bit : 0u);
+  int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
+  uint32_t err = 0;
+  // (block < n_blocks: the padding bits behind the image's last block are not symbols)
+  bool live = active && bit < end_bit && block < img.n_blocks;
+  for (uint32_t step = 0;; step++) {
+    if ((step & 3u) == 0) {
+      if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+      if (live) s.top_up();
+    }
+    if (live) {
+      const uint32_t before = st.nblk;
+      if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, coef + (int64_t)(block + st.nblk) * 64)) {
+        err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
+        live = false;
+      } else {
+        (void)before;
+        live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < img.n_blocks;
+      }
+    }
+  }
+  if (active) {
+    const bool last = ci + 1 == img.n_chunks;
+    if (last) {
+      if (block + st.nblk != img.n_blocks || st.k != 0) err |= 2;  // the scan ends before the frame does
+    } else if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta) {
+      err |= 4;  // this chunk does not end where the synchronisation passes said it would
+    }
+    if (err) atomicOr(p.status + wg.image, err);
+  }
+}
+
+// the DC pass: blocks hold DC differences; per component, turn them into the running predictor
+// (grid: 3 workgroups per image of the sync list)
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_dc_kernel(const JbHuffLaunch p) {
+  __shared__ int32_t part[kJbHuffLanes];
+  const uint32_t which = blockIdx.x / 3, c = blockIdx.x % 3;
+  const uint32_t image = p.sync_images[which];
+  const JbHuffImage img = p.images[image];
+  const uint32_t nb = img.ny + 2, n_mcus = img.n_blocks / nb;
+  const uint32_t n = c == 0 ? n_mcus * img.ny : n_mcus;  // blocks of this component
+  int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
+  auto at = [&](uint32_t j) -> int16_t * {  // DC coefficient of the component's j-th block in decode order
+    const uint32_t b = c == 0 ? (j / img.ny) * nb + j % img.ny : j * nb + img.ny + (c - 1);
+    return coef + (int64_t)b * 64;
+  };
+  const uint32_t per = (n + kJbHuffLanes - 1) / kJbHuffLanes;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int32_t sum = 0;
+  for (uint32_t j = lo; j < hi; j++) sum += *at(j);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < kJbHuffLanes; i++) {
+      const int32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  int32_t run = part[threadIdx.x];
+  bool bad = false;
+  for (uint32_t j = lo; j < hi; j++) {
+    int16_t *d = at(j);
+    run += *d;
+    bad |= run < -32768 || run > 32767;
+    *d = (int16_t)run;
+  }
+  if (bad) atomicOr(p.status + image, 1u);
+}
+
 hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
-  if (p.n_wgs <= 0) return hipSuccess;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(jb_huff_kernel, dim3((unsigned)p.n_wgs), dim3(kJbHuffLanes), 0, stream, p);
+  if (p.n_wgs > 0) hipLaunchKernelGGL(jb_huff_kernel, dim3((unsigned)p.n_wgs), dim3(kJbHuffLanes), 0, stream, p);
+  if (p.n_sync_wgs > 0 && p.n_sync_images > 0) {
+    const dim3 grid((unsigned)p.n_sync_wgs), block(kJbHuffLanes);
+    const JbChunkState *fin = nullptr;
+    for (int r = 0; r < kJbSyncRounds; r++) {
+      const JbChunkState *src = (r & 1) ? p.state_a : p.state_b;
+      JbChunkState *dst = (r & 1) ? p.state_b : p.state_a;
+      hipLaunchKernelGGL(jb_huff_sync_kernel, grid, block, 0, stream, p, r, src, dst);
+      fin = dst;
+    }
+    hipLaunchKernelGGL(jb_huff_scan_kernel, dim3((unsigned)p.n_sync_images), block, 0, stream, p, fin);
+    hipLaunchKernelGGL(jb_huff_write_kernel, grid, block, 0, stream, p, fin);
+    hipLaunchKernelGGL(jb_huff_dc_kernel, dim3((unsigned)p.n_sync_images * 3u), block, 0, stream, p);
+  }
   return hipGetLastError();
 }

@@ -20,12 +20,14 @@ def seeds():
     for i, (w, h, hs, vs, ri) in enumerate([(200, 120, 2, 2, 3), (333, 211, 1, 1, 7), (160, 96, 2, 1, 1), (97, 131, 1, 2, 5), (640, 360, 2, 2, 40)]):
         coef, q = synth.synth_blocks(w, h, hs, vs, 60 + i)
         out.append(bytearray(synth.encode_jpeg(coef, w, h, hs, vs, q, restart_interval=ri)))
+        if i % 2 == 0:  # the same without restart intervals: the self-synchronising decoder
+            out.append(bytearray(synth.encode_jpeg(coef, w, h, hs, vs, q)))
     try:
         import io
         from PIL import Image
         rng = np.random.default_rng(3)
         img = np.clip(np.cumsum(rng.normal(0, 5, (151, 227, 3)), axis=1) + 128, 0, 255).astype(np.uint8)
-        for kw in ({"restart_marker_blocks": 4}, {"restart_marker_rows": 1, "optimize": True}):
+        for kw in ({"restart_marker_blocks": 4}, {"restart_marker_rows": 1, "optimize": True}, {}, {"optimize": True}):
             b = io.BytesIO()
             Image.fromarray(img).save(b, "JPEG", quality=88, subsampling=2, **kw)
             out.append(bytearray(b.getvalue()))
