@@ -528,7 +528,8 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // upload a packed submission (jb_huff_pack_) and launch the decoder: image i's coefficient blocks
 // land at d_out + i * coef_stride bytes, its status word at s.d_status[i]
-int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up) {
+int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up,
+               int sync_rounds = kJbSyncRounds) {
   if (lay.device_total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
     if (s.d_blob) (void)hipFree(s.d_blob);
     s.d_blob = nullptr, s.blob_cap = 0;
@@ -561,6 +562,7 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
   p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
+  p.sync_rounds = sync_rounds;
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
 }
@@ -699,12 +701,21 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
   JbHuffLayout lay;
   rc = pack_into_slot(ctx, s, jobs, 1, job->geo.coef_bytes, &lay);
   const size_t coef_bytes = (size_t)job->geo.coef_bytes;
+  const int n_chunks = (int)job->img.n_chunks;
   delete job;  // (everything it held is in the pinned blob now)
   if (rc) return rc;
-  rc = huff_stage(ctx, s, s.h_blob, lay, coef_bytes, d_coef, ctx->stream);
-  if (rc) return rc;
-  JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-  JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // Scans without restart intervals: the chunk lanes fall into step within a few passes on ordinary
+  // data; dense adversarial data (hardly any EOB to meet at) can take more -- status bit 2 says "not
+  // yet", and correct states spread by at least one chunk per pass, so n_chunks passes always do.
+  int rounds = kJbSyncRounds;
+  for (;;) {
+    rc = huff_stage(ctx, s, s.h_blob, lay, coef_bytes, d_coef, ctx->stream, rounds);
+    if (rc) return rc;
+    JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(s.h_status[0] & 4u) || rounds > n_chunks) break;
+    rounds = rounds < 64 ? 64 : n_chunks + 1;
+  }
   s.n_status = 1;
   return check_status(ctx, s);
 }

@@ -45,7 +45,7 @@ struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart int
 };
 
 constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder
-constexpr int kJbSyncRounds = 8;         // synchronisation passes before the writing pass (which verifies)
+constexpr int kJbSyncRounds = 8;         // synchronisation passes before the writing pass (which verifies): the default
 
 // Exit state of a chunk's decode: where the first symbol of the next chunk starts and in which state
 struct JbChunkState {
@@ -69,6 +69,7 @@ struct JbHuffLaunch {
   const uint32_t *sync_images; // ... and their indices (device)
   JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each
   uint32_t *base;              // device scratch: index of the block a chunk starts in
+  int32_t sync_rounds;         // synchronisation passes (>= 1); n_chunks of them always suffice
 };
 
 constexpr int kJbHuffLanes = 256;  // restart intervals per workgroup (LDS: 18 KiB of tables + a 64-byte stream ring per lane)

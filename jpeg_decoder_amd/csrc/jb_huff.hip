@@ -564,7 +564,8 @@ hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
   if (p.n_sync_wgs > 0 && p.n_sync_images > 0) {
     const dim3 grid((unsigned)p.n_sync_wgs), block(kJbHuffLanes);
     const JbChunkState *fin = nullptr;
-    for (int r = 0; r < kJbSyncRounds; r++) {
+    const int rounds = p.sync_rounds > 0 ? p.sync_rounds : kJbSyncRounds;
+    for (int r = 0; r < rounds; r++) {
       const JbChunkState *src = (r & 1) ? p.state_a : p.state_b;
       JbChunkState *dst = (r & 1) ? p.state_b : p.state_a;
       hipLaunchKernelGGL(jb_huff_sync_kernel, grid, block, 0, stream, p, r, src, dst);
