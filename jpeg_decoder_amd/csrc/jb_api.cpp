@@ -562,7 +562,9 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
   p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
-  p.sync_rounds = sync_rounds;
+  // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
+  static const int env_rounds = getenv("JPEGBLK_SYNC_ROUNDS") ? atoi(getenv("JPEGBLK_SYNC_ROUNDS")) : 0;
+  p.sync_rounds = (env_rounds > 0 && sync_rounds == kJbSyncRounds) ? env_rounds : sync_rounds;
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
 }
