@@ -210,18 +210,21 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
                          uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes,
                          int n_threads);
 /* The entropy stage ON THE DEVICE (beyond the reference, whose decodeHuffman() -- jpeg.cpp:405-446 --
- * is serial host code): for baseline files with restart intervals (DRI; e.g. the reference's
- * images/img4.jpg) the host only parses the headers and removes the byte stuffing; every restart
- * interval is then Huffman-decoded by its own GPU lane (the DC predictors reset at each restart,
- * jpeg.cpp:419-425, so intervals are independent) with the host decoder's lookup tables, straight
- * into the coefficient layout described above.  d_coef is a DEVICE pointer (16-byte aligned,
+ * is serial host code): the host only parses the headers and removes the byte stuffing.  Files with
+ * restart intervals (DRI; e.g. the reference's images/img4.jpg): every interval is Huffman-decoded
+ * by its own GPU lane (the DC predictors reset at each restart, jpeg.cpp:419-425, so intervals are
+ * independent).  Files without (the reference's other bundled images, most files anywhere): the
+ * self-synchronising decoder -- one lane per 256-byte chunk of the scan, a few passes in which the
+ * lanes fall into step with the true symbol sequence, a verified writing pass, a DC pass.  Both
+ * write straight into the coefficient layout described above.  d_coef is a DEVICE pointer (16-byte aligned,
  * capacity coef_cap_bytes); the result is integer-exact with jb_entropy_decode.  Synchronous.
- * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (no DRI, markers that do not match
- * the frame, more than two DC or AC tables, progressive ...) -- use jb_entropy_decode.
+ * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (restart markers that do not match
+ * the frame, more than two DC or AC tables, progressive, grayscale ...) -- use jb_entropy_decode.
  * JB_ERR_FORMAT: corrupt data.  jb_decode_file / jb_decode_memory / jb_batch_decoder take this path
- * when asked to -- environment JPEGBLK_GPU_HUFFMAN=1: files with 16 or more restart intervals, =2:
- * any file with DRI -- and fall back to the host decoder per image for whatever it does not take or
- * flags as corrupt.  The default is the host decoder (north_star's split). */
+ * when asked to -- environment JPEGBLK_GPU_HUFFMAN=1: files with 16 or more restart intervals and
+ * files without DRI of 4 KB of scan or more, =2: any number of intervals -- and fall back to the host
+ * decoder per image for whatever it does not take or flags (corrupt data; chunks that did not
+ * synchronise).  The default is the host decoder (north_star's split). */
 int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                              uint16_t *qtabs /* 4*64, may be NULL */, int16_t *d_coef, size_t coef_cap_bytes);
 /* How many images this context has decoded with the entropy stage on the device (through

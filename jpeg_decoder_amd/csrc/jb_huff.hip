@@ -1,7 +1,8 @@
 // jb_huff.hip -- Huffman decoding of baseline scans ON THE DEVICE, one lane per restart interval
 // (gfx950).  Beyond the reference (its decodeHuffman, jpeg.cpp:405-446, is serial host code and
 // north_star keeps the entropy stage on the host): SURVEY.md section 8(f) rank 4.  Files with DRI
-// take this path; everything else stays on the host decoder (jb_frontend.cpp).
+// take the interval decoder below, files without the self-synchronising decoder further down;
+// progressive / grayscale / multi-scan files stay on the host (jb_frontend_ext.cpp).
 //
 // Why it works: the DC predictors reset at every restart marker (T.81 F.2.1.3.1; reference
 // jpeg.cpp:419-425), so the intervals of a scan are independent bit streams -- after the host has
