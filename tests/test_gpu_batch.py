@@ -106,14 +106,19 @@ def test_batch_decoder_config5_8192_420(jb, files_8192, monkeypatch, arena, devi
             _check(imgs, st, tm, want + want)
 
 
+@pytest.mark.parametrize("entropy", ["host", "device"])
 @pytest.mark.parametrize("devices", [None, [0, 0]])
 @pytest.mark.parametrize("threads", [1, 8])
 @pytest.mark.parametrize("arena", [False, True])
-def test_batch_decoder_mixed_sizes_and_samplings(jb, oracle, tmp_path, arena, threads, devices):
+def test_batch_decoder_mixed_sizes_and_samplings(jb, oracle, tmp_path, monkeypatch, arena, threads, devices, entropy):
     """One 2048x1536 4:4:4 file (18.9 MB of coefficients, 9.4 MB of pixels) among 44 files of
     679x451 4:2:0: the ring slots are sized by the large image, and a group of small 4:2:0 images
     that fits its coefficient capacity (19 images) would overflow its pixel capacity (10) -- groups
     are bounded by both."""
+    if entropy == "device":  # no restart intervals in these files: the self-synchronising decoder
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
+    else:
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
     big_p, big_w = _write_files(str(tmp_path), "big", 2048, 1536, 1, 1, 1, 1, 0, oracle)
     small_p, small_w = _write_files(str(tmp_path), "small", 679, 451, 2, 2, 44, 3, 0, oracle)
     paths = small_p[:5] + big_p + small_p[5:]
@@ -122,6 +127,23 @@ def test_batch_decoder_mixed_sizes_and_samplings(jb, oracle, tmp_path, arena, th
     with jb.BatchDecoder(threads, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
         imgs, st, tm = dec.run(paths)
         _check(imgs, st, tm, want)
+        assert dec.device_entropy_images == (len(paths) if entropy == "device" else 0)
+
+
+def test_batch_decoder_device_entropy_on_the_reference_images(jb, monkeypatch):
+    """The reference's six bundled baseline images (five without restart markers: the
+    self-synchronising decoder; img4 with DRI = 100: the interval decoder), three times over, through
+    the batch decoder with the entropy stage on the device: the golden pixels of the reference."""
+    from conftest import BASELINE_IMAGES, GOLD, load_golden
+    monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
+    names = BASELINE_IMAGES * 3
+    paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
+    with jb.BatchDecoder(4, 0) as dec:
+        imgs, st, tm = dec.run(paths)
+        assert tm["rc"] == 0 and all(x == 0 for x in st), (tm, st)
+        assert dec.device_entropy_images == len(paths)
+    for n, got in zip(names, imgs):
+        assert np.array_equal(got, load_golden(n)[3]), n
 
 
 def test_multi_device_decoder_rejects_and_reports(jb, tmp_path):
