@@ -561,6 +561,7 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.sync_images = (const uint32_t *)(d + lay.off_sync_img);
   p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
   p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
+  p.state_in = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_in);
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
   // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
   static const int env_rounds = getenv("JPEGBLK_SYNC_ROUNDS") ? atoi(getenv("JPEGBLK_SYNC_ROUNDS")) : 0;
@@ -716,7 +717,7 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
     JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!(s.h_status[0] & 4u) || rounds > n_chunks) break;
-    rounds = rounds < 64 ? 64 : n_chunks + 1;
+    rounds = rounds < 128 ? 128 : n_chunks + 1;
   }
   s.n_status = 1;
   return check_status(ctx, s);
@@ -973,7 +974,8 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   // device-only scratch behind the uploaded bytes
   lay->off_state_a = a16(lay->total);
   lay->off_state_b = a16(lay->off_state_a + n_chunks * sizeof(JbChunkState));
-  lay->off_base = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
+  lay->off_state_in = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
+  lay->off_base = a16(lay->off_state_in + n_chunks * sizeof(JbChunkState));
   lay->device_total = a16(lay->off_base + n_chunks * 4);
   lay->n = n;
   lay->n_wg = (int)n_wg;

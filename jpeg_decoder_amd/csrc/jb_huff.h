@@ -45,7 +45,8 @@ struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart int
 };
 
 constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder
-constexpr int kJbSyncRounds = 8;         // synchronisation passes before the writing pass (which verifies): the default
+constexpr int kJbSyncRounds = 16;        // synchronisation passes before the writing pass (which verifies): the default;
+                                         // a lane whose start state did not change since the last pass skips its decode
 
 // Exit state of a chunk's decode: where the first symbol of the next chunk starts and in which state
 struct JbChunkState {
@@ -67,7 +68,8 @@ struct JbHuffLaunch {
   int32_t n_sync_wgs;
   int32_t n_sync_images;       // images with n_chunks > 0 ...
   const uint32_t *sync_images; // ... and their indices (device)
-  JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each
+  JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each: exit states of the passes, ping-pong
+  JbChunkState *state_in;           // device scratch: the start state each chunk was last decoded from
   uint32_t *base;              // device scratch: index of the block a chunk starts in
   int32_t sync_rounds;         // synchronisation passes (>= 1); n_chunks of them always suffice
 };
@@ -108,7 +110,7 @@ struct JbHuffLayout {
   int64_t coef_stride = 0;
   // the self-synchronising decoder's part: its workgroup list and image list (uploaded), and the
   // device-only scratch behind the uploaded bytes (chunk states x 2, chunk bases)
-  size_t off_sync_wg = 0, off_sync_img = 0, off_state_a = 0, off_state_b = 0, off_base = 0, device_total = 0;
+  size_t off_sync_wg = 0, off_sync_img = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_base = 0, device_total = 0;
   int n_sync_wg = 0, n_sync_images = 0;
 };
 // Is the device decoder worth taking for this image?  Restart-interval mode: at least `min_intervals`

@@ -303,8 +303,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
 //   sync pass r > 0  every lane decodes its chunk again, now from the exit state its left neighbour
 //                    recorded in pass r - 1 (lane 0: from the true start).  Correct states spread
 //                    from the left, at least one chunk per pass, in practice across the whole scan
-//                    in two or three passes because most lanes had fallen into step inside their
-//                    own chunk already;
+//                    in a few passes because most lanes had fallen into step inside their own chunk
+//                    already.  A lane whose start state is the one it decoded from in the pass before
+//                    keeps its exit state and does nothing: passes after convergence cost a launch;
 //   scan             exclusive prefix sum of the blocks completed per chunk: the block each chunk starts in;
 //   write pass       every lane decodes its chunk once more from its neighbour's final exit state
 //                    and this time stores the coefficients (DC as differences) -- and VERIFIES that
@@ -383,15 +384,27 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const uint32_t total_bits = img.scan_len * 8u;
   uint32_t bit = 0;
   ChunkLane st{0, 0, 0};
-  if (active && ci > 0) {
-    if (round == 0) {
-      bit = ci * (kJbChunkBytes * 8u);
-    } else {
-      const JbChunkState prev = src[img.state_off + ci - 1];
-      bit = prev.bitpos;
-      st.k = prev.meta & 0xffu;
-      st.blk = (prev.meta >> 8) & 0xffu;
+  bool skip = false;  // the start state is the one this chunk was decoded from last time: same exit state
+  if (active) {
+    JbChunkState in{0, 0};
+    if (ci > 0) {
+      if (round == 0) {
+        in.bitpos = ci * (kJbChunkBytes * 8u);
+      } else {
+        const JbChunkState prev = src[img.state_off + ci - 1];
+        in.bitpos = prev.bitpos;
+        in.meta = prev.meta & 0xffffu;  // k and the block's place in the MCU
+      }
     }
+    if (round > 0) {
+      const JbChunkState last = p.state_in[img.state_off + ci];
+      skip = last.bitpos == in.bitpos && last.meta == in.meta;
+    }
+    if (skip) dst[img.state_off + ci] = src[img.state_off + ci];  // (this chunk's exit state of the pass before)
+    else p.state_in[img.state_off + ci] = in;
+    bit = in.bitpos;
+    st.k = in.meta & 0xffu;
+    st.blk = (in.meta >> 8) & 0xffu;
   }
   uint32_t end_bit = (ci + 1) * (kJbChunkBytes * 8u);
   if (end_bit > total_bits) end_bit = total_bits;
@@ -400,8 +413,8 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   s.base = p.scan + img.scan_off;
   s.limit = (img.scan_len + 48u) & ~15u;
   s.ring = rings + tid * kRing;
-  open_at_bit(s, active ? bit : 0u);
-  bool live = active && bit < end_bit;
+  open_at_bit(s, (active && !skip) ? bit : 0u);
+  bool live = active && !skip && bit < end_bit;
   for (uint32_t step = 0;; step++) {
     if ((step & 3u) == 0) {
       if (__builtin_amdgcn_ballot_w64(live) == 0) break;
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       live = (uint32_t)s.bitpos() < end_bit;
     }
   }
-  if (active) dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
+  if (active && !skip) dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
 }
 
 // exclusive prefix sum of the blocks completed per chunk: one workgroup per image

@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--modes", default="malloc,arena")
     ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
-                    "restart intervals can take the device-side entropy decoder: JPEGBLK_GPU_HUFFMAN=1")
+                    "JPEGBLK_GPU_HUFFMAN=1 moves the entropy stage to the device for files with AND without restart intervals")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
