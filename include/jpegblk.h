@@ -220,11 +220,13 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
  * capacity coef_cap_bytes); the result is integer-exact with jb_entropy_decode.  Synchronous.
  * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (restart markers that do not match
  * the frame, more than two DC or AC tables, progressive, grayscale ...) -- use jb_entropy_decode.
- * JB_ERR_FORMAT: corrupt data.  jb_decode_file / jb_decode_memory / jb_batch_decoder take this path
- * when asked to -- environment JPEGBLK_GPU_HUFFMAN=1: files with 16 or more restart intervals and
- * files without DRI of 4 KB of scan or more, =2: any number of intervals -- and fall back to the host
+ * JB_ERR_FORMAT: corrupt data.  The BATCH decoders (jb_decode_batch, jb_batch_decoder_*) take this
+ * path by default for every image it accepts (16 restart intervals / 4 KB of scan or more; measured
+ * 1.06x to 2.6x the rate of 16 host threads for a tenth of their CPU time) and fall back to the host
  * decoder per image for whatever it does not take or flags (corrupt data; chunks that did not
- * synchronise).  The default is the host decoder (north_star's split). */
+ * synchronise); environment JPEGBLK_GPU_HUFFMAN=0 keeps the entropy stage on the host threads
+ * (north_star's split), =2 drops the size threshold.  The single-image jb_decode_file /
+ * jb_decode_memory stay on the host decoder unless JPEGBLK_GPU_HUFFMAN=1 or 2 is set. */
 int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                              uint16_t *qtabs /* 4*64, may be NULL */, int16_t *d_coef, size_t coef_cap_bytes);
 /* How many images this context has decoded with the entropy stage on the device (through
@@ -242,12 +244,14 @@ void jb_free(void *p);
  * mcuWidthReal / mcuHeightReal (jpeg.cpp:794-795, computed at :118-125). */
 int jb_ctx_last_desc(const jb_ctx *ctx, jb_image_desc *out);
 
-/* Batch of files: the multi-image form of decode(path) (BASELINE.json configs 4-5: "host Huffman
- * on all cores overlapped with device IDCT").  `n_threads` host threads each own a context on
- * `device_id` (own stream + pinned staging ring) and walk the files i = t, t + n_threads, ...:
- * parse + Huffman-decode image i into pinned memory, submit it, and collect image i-1 while the
- * device works -- so the entropy stage of one image overlaps the copies and the kernel of
- * another, within a thread and across threads.  Per file: rgb[i] (malloc'd, tight rows; NULL on
+/* Batch of files: the multi-image form of decode(path) (BASELINE.json configs 4-5).  `n_threads`
+ * host threads share one context on `device_id` (pinned staging ring) and walk the files
+ * i = t, t + n_threads, ...  With JPEGBLK_GPU_HUFFMAN=0 -- north_star's split, "host Huffman on all
+ * cores overlapped with device IDCT" -- a thread parses and Huffman-decodes image i into pinned
+ * memory, submits it, and collects image i-1 while the device works, so the entropy stage of one
+ * image overlaps the copies and the kernel of another, within a thread and across threads.  By
+ * default the threads only parse, remove the byte stuffing and pack, and the entropy stage runs on
+ * the device too (jb_entropy_decode_device above).  Per file: rgb[i] (malloc'd, tight rows; NULL on
  * failure, release with jb_free), widths[i], heights[i], statuses[i] (a jb_status).  `times`
  * (optional, 4 doubles) receives seconds: wall, summed entropy-decode, summed submit+wait,
  * summed file read.  Returns JB_OK when every file decoded, else the first failing status. */

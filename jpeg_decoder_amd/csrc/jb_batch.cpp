@@ -277,16 +277,26 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
     bool on_device = false;              // the group's entropy stage ran on the device (jb_huff.hip)
   } grp[kSlots];
-  // Files with restart intervals can have their entropy stage on the device; this thread then only
-  // parses, removes the byte stuffing and packs.  Opt-in: JPEGBLK_GPU_HUFFMAN=1 (files with 16
-  // intervals or more) or =2 (any file with DRI).  A group is all-device or all-host.
+  // Where the entropy stage runs.  The batch decoder's default is the DEVICE for every baseline image
+  // the device decoders take (restart intervals: one lane per interval; none: the self-synchronising
+  // decoder), 16 intervals / chunks or more: measured against 16 host threads it is 1.06x (8,192 small
+  // images) to 2.6x (4096x4096 files) as fast end to end for a tenth of the host CPU time (DESIGN.md
+  // section 9); this thread then only parses, removes the byte stuffing and packs.  What the device
+  // decoders refuse or flag goes through the host decoder, image by image.  JPEGBLK_GPU_HUFFMAN=0
+  // keeps the entropy stage on the host threads (north_star's split), =2 drops the 16-interval
+  // threshold.  A group is all-device or all-host.
   // (A hybrid -- a quarter of the threads feeding the device decoder with 60 % of the files, the rest
   // decoding on the host -- was measured and is slower than either pure mode: 1,885 images/s against
   // 2,681 host / 2,498 device on PIL 1080p files; large group downloads and many small uploads and
   // downloads at once share the link badly.  Removed.)
   const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-  const bool dev_entropy = knob && (knob[0] == '1' || knob[0] == '2');
+  const bool dev_entropy = !(knob && knob[0] == '0');
   const uint32_t min_intervals = (knob && knob[0] == '2') ? 1u : 16u;
+  int dev_max_group = kMaxGroup;  // images per device-entropy group (JPEGBLK_DEV_MAX_GROUP: A/B only)
+  if (const char *e = getenv("JPEGBLK_DEV_MAX_GROUP")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= kMaxGroup) dev_max_group = v;
+  }
   std::vector<uint16_t> qtabs;
   auto index_of = [&](int k) { return (*r.lists)[(size_t)t][(size_t)k]; };
   auto report = [&](int i, int st, const std::string &text) {
@@ -379,7 +389,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     // it is bounded by the ring slot (and, without an arena, by the pinned pixel staging)
     size_t droom_c = r.dev_cap_coef / coef_bytes, droom_p = (use_arena ? r.dev_cap_rgb : lane->cap_rgb) / rgb_bytes;
     int room_dev = (int)(droom_c < droom_p ? droom_c : droom_p);
-    if (room_dev > kMaxGroup) room_dev = kMaxGroup;
+    if (room_dev > dev_max_group) room_dev = dev_max_group;
     if (room_dev < 1) room_dev = 1;
     // entropy-decode consecutive images of the head's geometry into the slot, back to back -- or,
     // for files with restart intervals, only ready them for the device decoder
@@ -615,13 +625,13 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // only as many lanes as it has restart intervals, each a long serial decode, and a launch takes
   // that long whatever the group size -- measured on 1,024 PIL 1080p files: 2,626 images/s in groups
   // of 20, 3,947 in groups of 64.  The ring slots are sized for a thread's whole share of the batch,
-  // up to JPEGBLK_DEV_GROUP_MB (default 1024); the threads' pinned buffers keep their size.
+  // up to JPEGBLK_DEV_GROUP_MB (default 512); the threads' pinned buffers keep their size.
   size_t ring_bytes = 0;
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    if (knob && (knob[0] == '1' || knob[0] == '2')) {
+    if (!(knob && knob[0] == '0')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
-      const long mb = e ? atol(e) : 1024;
+      const long mb = e ? atol(e) : 512;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
       size_t share = (size_t)((n_paths + n_threads - 1) / (n_threads > 0 ? n_threads : 1));
       if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;

@@ -64,13 +64,13 @@ def files_8192(tmp_path_factory, oracle):
 def test_batch_decoder_config4_1080p_444(jb, files_1080p, monkeypatch, arena, devices, entropy):
     """BASELINE config 4 (one GPU's share, as files): 32 x 1920x1080 4:4:4, 8 threads.  The files
     carry restart intervals (one per MCU row): with the entropy stage on the host threads
-    (the default) and on the device (JPEGBLK_GPU_HUFFMAN=1)."""
+    (JPEGBLK_GPU_HUFFMAN=0, north_star's split) and on the device (the batch decoder's default)."""
     paths, want = files_1080p
     total = sum((w.size + 255) // 256 * 256 for w in want)
-    if entropy == "host":
+    if entropy == "host":  # north_star's split: Huffman on the host threads
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:                  # the batch decoder's default
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
-    else:
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     for group_mb in (None, "0"):
         if group_mb is None:
             monkeypatch.delenv("JPEGBLK_GROUP_MB", raising=False)
@@ -92,10 +92,10 @@ def test_batch_decoder_config5_8192_420(jb, files_8192, monkeypatch, arena, devi
     device IDCT", restart-interval splitting on (more host threads than files) -- and on the device."""
     paths, want = files_8192
     total = sum((w.size + 255) // 256 * 256 for w in want)
-    if entropy == "host":
+    if entropy == "host":  # north_star's split: Huffman on the host threads
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:                  # the batch decoder's default
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
-    else:
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
     with jb.BatchDecoder(8, 0, arena_bytes=total if arena else 0, devices=devices) as dec:
         imgs, st, tm = dec.run(paths)
         _check(imgs, st, tm, want)
@@ -115,10 +115,10 @@ def test_batch_decoder_mixed_sizes_and_samplings(jb, oracle, tmp_path, monkeypat
     679x451 4:2:0: the ring slots are sized by the large image, and a group of small 4:2:0 images
     that fits its coefficient capacity (19 images) would overflow its pixel capacity (10) -- groups
     are bounded by both."""
-    if entropy == "device":  # no restart intervals in these files: the self-synchronising decoder
-        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
-    else:
+    if entropy == "device":  # (the default) no restart intervals in these files: the self-synchronising decoder
         monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    else:
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
     big_p, big_w = _write_files(str(tmp_path), "big", 2048, 1536, 1, 1, 1, 1, 0, oracle)
     small_p, small_w = _write_files(str(tmp_path), "small", 679, 451, 2, 2, 44, 3, 0, oracle)
     paths = small_p[:5] + big_p + small_p[5:]
@@ -135,7 +135,7 @@ def test_batch_decoder_device_entropy_on_the_reference_images(jb, monkeypatch):
     self-synchronising decoder; img4 with DRI = 100: the interval decoder), three times over, through
     the batch decoder with the entropy stage on the device: the golden pixels of the reference."""
     from conftest import BASELINE_IMAGES, GOLD, load_golden
-    monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
+    monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
     names = BASELINE_IMAGES * 3
     paths = [os.path.join(GOLD, "images", n + ".jpg") for n in names]
     with jb.BatchDecoder(4, 0) as dec:
@@ -188,7 +188,7 @@ def test_batch_decoder_device_entropy_falls_back_per_image(jb, oracle, tmp_path,
     """A batch of DRI files of one geometry with one damaged file in the middle: the group goes
     through the device entropy decoder, the damaged image is flagged by its status word and handed to
     the host decoder (the authority), which rejects it; every other image decodes."""
-    monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "1")
+    monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
     paths, want = _write_files(str(tmp_path), "dri", 640, 360, 2, 2, 9, 3, 10, oracle)
     data = bytearray(open(paths[4], "rb").read())
     sos = data.index(b"\xff\xda")

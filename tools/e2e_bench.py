@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end regimes of SURVEY 8(d) beside the kernel-only number of bench.py:
-  (1) full decode(path): JPEG files -> host Huffman on T threads -> pinned H2D -> kernel -> D2H
-      (jb_decode_batch), on synthetic baseline JPEGs written with PIL (quality 90, no Huffman
-      optimisation -- the kind of file the reference's front end accepts);
+  (1) full decode(path): JPEG files -> T host threads -> pinned H2D -> kernels -> D2H
+      (jb_batch_decoder), on synthetic baseline JPEGs written with PIL (quality 90, no Huffman
+      optimisation -- the kind of file the reference's front end accepts).  The entropy stage runs
+      on the device by default (the threads parse, de-stuff and pack); JPEGBLK_GPU_HUFFMAN=0 puts it
+      on the host threads (north_star's split);
   (2) PCIe-inclusive block pipeline: pre-decoded coefficient blocks in pinned host memory ->
       jb_submit/jb_wait ring -> pixels in pinned host memory (no Huffman).
 No rate is reported for unchecked pixels: before timing, every distinct file is decoded once through
@@ -105,7 +107,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--modes", default="malloc,arena")
     ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
-                    "JPEGBLK_GPU_HUFFMAN=1 moves the entropy stage to the device for files with AND without restart intervals")
+                    "the batch decoder decodes the entropy stage on the device by default, JPEGBLK_GPU_HUFFMAN=0 on the host threads")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
@@ -121,7 +123,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         distinct = (make_jpegs if args.source == "pil" else make_jpegs_writer)(args.distinct, w, h, args.sub, d, args.dri)
         out["restart_interval_rows"] = args.dri
-        out["JPEGBLK_GPU_HUFFMAN"] = os.environ.get("JPEGBLK_GPU_HUFFMAN", "(unset: host entropy decoder)")
+        out["JPEGBLK_GPU_HUFFMAN"] = os.environ.get("JPEGBLK_GPU_HUFFMAN", "(unset: the batch decoder's default = entropy stage on the device)")
         from jpeg_decoder_amd.shard import shard_images
         mine = shard_images(args.n, rank, world)           # image i -> rank i % world
         paths = [distinct[i % len(distinct)] for i in mine]
