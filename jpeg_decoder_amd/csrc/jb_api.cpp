@@ -562,6 +562,8 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
   p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
   p.state_in = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_in);
+  p.chunks = (const JbChunkDesc *)(d + lay.off_chunks);
+  p.dcsum = (uint32_t *)((uint8_t *)s.d_blob + lay.off_dcsum);
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
   // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
   static const int env_rounds = getenv("JPEGBLK_SYNC_ROUNDS") ? atoi(getenv("JPEGBLK_SYNC_ROUNDS")) : 0;
@@ -617,7 +619,9 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   hipStream_t up = ps, down = ps;
   // (all downloads of these submissions on the one download stream instead: 2,175 against 2,640
-  // images/s on PIL 1080p files -- not taken)
+  // images/s on PIL 1080p files -- not taken; JPEGBLK_DEV_DOWN=1 is that variant, for A/B runs)
+  static const bool one_down = getenv("JPEGBLK_DEV_DOWN") && getenv("JPEGBLK_DEV_DOWN")[0] == '1';
+  if (one_down && ctx->stream2) down = ctx->stream2;
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, jobs ? jobs[i]->qtabs : qtabs_in + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
@@ -932,11 +936,14 @@ size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n) {
     n_starts += jobs[i]->starts.size();
     scan_bytes += ((jobs[i]->scan.size() + 15) & ~(size_t)15);
   }
-  // (the self-synchronising decoder's lists: a workgroup per kJbHuffLanes chunks, an index per image)
-  size_t n_sync_wg = 0;
-  for (int i = 0; i < n; i++) n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+  // (the self-synchronising decoder's lists: a workgroup per kJbHuffLanes chunks, an index per image, a descriptor per chunk)
+  size_t n_sync_wg = 0, n_chunks = 0;
+  for (int i = 0; i < n; i++) {
+    n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_chunks += jobs[i]->img.n_chunks;
+  }
   return (size_t)n * sizeof(JbHuffImage) + (n_wg + n_sync_wg) * sizeof(JbHuffWg) + (size_t)n * (sizeof(JbHuffTables) + 4) + n_starts * 4 +
-         scan_bytes + 128;
+         n_chunks * sizeof(JbChunkDesc) + scan_bytes + 160;
 }
 
 int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint8_t *h, JbHuffLayout *lay) {
@@ -969,14 +976,16 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   lay->off_starts = lay->off_tab + sets.size() * sizeof(JbHuffTables);
   lay->off_sync_wg = a16(lay->off_starts + n_starts * 4);
   lay->off_sync_img = a16(lay->off_sync_wg + n_sync_wg * sizeof(JbHuffWg));
-  lay->off_scan = a16(lay->off_sync_img + n_sync_images * 4);
+  lay->off_chunks = a16(lay->off_sync_img + n_sync_images * 4);
+  lay->off_scan = a16(lay->off_chunks + n_chunks * sizeof(JbChunkDesc));
   lay->total = lay->off_scan + scan_bytes;
   // device-only scratch behind the uploaded bytes
   lay->off_state_a = a16(lay->total);
   lay->off_state_b = a16(lay->off_state_a + n_chunks * sizeof(JbChunkState));
   lay->off_state_in = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
-  lay->off_base = a16(lay->off_state_in + n_chunks * sizeof(JbChunkState));
-  lay->device_total = a16(lay->off_base + n_chunks * 4);
+  lay->off_dcsum = a16(lay->off_state_in + n_chunks * sizeof(JbChunkState));
+  lay->off_base = a16(lay->off_dcsum + n_chunks * 16);
+  lay->device_total = a16(lay->off_base + n_chunks * 16);
   lay->n = n;
   lay->n_wg = (int)n_wg;
   lay->n_sync_wg = (int)n_sync_wg;
@@ -1001,6 +1010,15 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
       for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
     } else {
       im[i].state_off = (uint32_t)chunk0;
+      // the chunks of every restart interval, from the interval's first byte (jb_chunks_of_)
+      JbChunkDesc *cd = (JbChunkDesc *)(h + lay->off_chunks) + chunk0;
+      uint32_t c = 0;
+      for (uint32_t seg = 0; seg + 1 < (uint32_t)j.starts.size(); seg++) {
+        const uint32_t k = jb_chunks_of_(j.starts[seg + 1] - j.starts[seg]);
+        if (c + k > j.img.n_chunks) return JB_ERR_STATE;
+        for (uint32_t q = 0; q < k; q++) cd[c++] = JbChunkDesc{j.starts[seg] + q * kJbChunkBytes, seg | (q == 0 ? 0x80000000u : 0u)};
+      }
+      if (c != j.img.n_chunks) return JB_ERR_STATE;
       chunk0 += j.img.n_chunks;
       simg[sn++] = (uint32_t)i;
       for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) swg[sw++] = JbHuffWg{(uint32_t)i, f};

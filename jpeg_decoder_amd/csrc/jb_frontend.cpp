@@ -325,9 +325,25 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   job->img.ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
   job->img.coef_off = 0;
   job->img.n_blocks = (uint32_t)(n_mcus * (job->img.ny + 2));
-  job->img.n_chunks = ri > 0 ? 0u : (uint32_t)((job->scan_len + kJbChunkBytes - 1) / kJbChunkBytes);
+  // Which decoder: one lane per restart interval when the intervals are short (many lanes, one
+  // launch), one lane per 256-byte chunk of every interval when they are long or there is only the
+  // one (a 1080p file with an interval per MCU row: 135 lanes of 720 blocks against 3,000 lanes).
+  // JPEGBLK_HUFF_MODE=interval / chunk forces one for files with DRI (tests, A/B runs).
+  bool chunked = ri == 0 || job->scan_len / (uint64_t)n_int >= kJbLongInterval;
+  if (ri > 0)
+    if (const char *m = getenv("JPEGBLK_HUFF_MODE")) chunked = m[0] == 'c' ? true : m[0] == 'i' ? false : chunked;
+  job->img.n_chunks = 0;
+  if (chunked) {
+    uint64_t n_chunks = 0;
+    for (size_t i = 0; i + 1 < job->starts.size(); i++) {
+      if (job->starts[i + 1] < job->starts[i]) return done(JB_ERR_FORMAT, "restart intervals out of order");
+      n_chunks += jb_chunks_of_(job->starts[i + 1] - job->starts[i]);
+    }
+    if (n_chunks > 0x3fffffffu) return done(JB_ERR_UNSUPPORTED, "scan too large for the device decoder: host decoder");
+    job->img.n_chunks = (uint32_t)n_chunks;
+  }
   job->img.state_off = job->img.reserved = 0;
-  if (ri == 0 && job->img.n_chunks == 0) return done(JB_ERR_FORMAT, "empty scan");
+  if (ri == 0 && job->scan_len == 0) return done(JB_ERR_FORMAT, "empty scan");
   return done(JB_OK, "");
 }
 
@@ -372,18 +388,26 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   if (!ctx) return jb_fail_(nullptr, JB_ERR_NULL, "jb_decode_memory: ctx is NULL");
   if (!jpeg || !rgb || !width || !height) return jb_fail_(ctx, JB_ERR_NULL, "jb_decode_memory: NULL pointer");
   *rgb = nullptr;
-  // Files with restart intervals can have their entropy stage on the device too (jb_huff.hip): the
-  // host then only parses the headers and removes the byte stuffing.  Opt-in -- JPEGBLK_GPU_HUFFMAN=1
-  // (16 intervals or more) or =2 (any number) -- because one image is at most a few hundred lanes
-  // of serial work: the device decoder wins on batches (jb_batch_decoder), not on a single
-  // image's latency.  Whatever the device decoder does not take or flags as corrupt goes
-  // through the host decoder below, which gives the precise answer.
+  // The entropy stage of a baseline file can run on the device too (jb_huff.hip): the host then only
+  // parses the headers and removes the byte stuffing.  One image is one latency-bound submission
+  // (a dozen and a half launches: about 1.3 ms whatever the size, then ~0.4 ms per megabyte of scan)
+  // against 5.5 ms per megabyte on one host core, so by default the device takes files of
+  // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.2-1.5 ms against 0.7 on the
+  // host, 1920x1080 4:4:4 (760 KB) 1.4-1.5 against 4.2, 8192x8192 4:2:0 (17 MB) 30 against 116
+  // (tools/single_latency.py).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
+  // =1: the device for every file with 16 restart intervals / chunks or more; =2: also fewer intervals.
+  // Whatever the device decoder does not take or flags as corrupt goes through the host decoder
+  // below, which gives the precise answer.
   {
+    constexpr size_t kAutoDeviceScan = (size_t)384 << 10;
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
+    const bool forced = knob && (knob[0] == '1' || knob[0] == '2');
+    const bool automatic = !knob || (knob[0] != '0' && !forced);
     const uint32_t min_int = (knob && knob[0] == '2') ? 1u : 16u;
-    if (knob && (knob[0] == '1' || knob[0] == '2')) {
+    if (forced || (automatic && jpeg_bytes >= kAutoDeviceScan)) {
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
-      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int)) {
+      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int) &&
+          (forced || job->scan_len >= kAutoDeviceScan)) {
         uint8_t *out = (uint8_t *)malloc((size_t)job->geo.rgb_bytes);
         if (!out) return jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
         const int rc = jb_decode_job_(ctx, job.get(), out, 3LL * job->desc.width);

@@ -1,6 +1,7 @@
 // jb_huff.h -- internal interface of the device-side entropy decoder (jb_huff.hip): Huffman
-// decoding of a baseline scan on the GPU, one lane per restart interval.  Not part of the public
-// ABI.  Plain C structs shared by the host code that fills them (jb_frontend.cpp, jb_api.cpp) and
+// decoding of a baseline scan on the GPU -- one lane per restart interval where the intervals are
+// short, one lane per 256-byte chunk of the scan (self-synchronising, verified) otherwise.  Not
+// part of the public ABI.  Plain C structs shared by the host code that fills them (jb_frontend.cpp, jb_api.cpp) and
 // the kernel that reads them.
 #pragma once
 #include <stdint.h>
@@ -32,9 +33,10 @@ struct JbHuffImage {
   int64_t coef_off;    // byte offset of the image's coefficient blocks in the output
   uint8_t dc_slot[4];  // table slot (0 / 1) of Y, Cb, Cr
   uint8_t ac_slot[4];
-  // scans WITHOUT restart intervals (n_int == 1): the self-synchronising decoder works on chunks
-  uint32_t n_chunks;   // kJbChunkBytes-byte chunks of the clean scan (0 = the interval decoder is used)
-  uint32_t state_off;  // index of the image's first entry in the chunk state / base arrays
+  // scans without restart intervals, and scans whose intervals are long: the self-synchronising
+  // decoder works on chunks of the intervals (a scan without DRI is one interval)
+  uint32_t n_chunks;   // chunks of the image (0 = the interval decoder is used): per interval ceil(bytes / kJbChunkBytes), at least 1
+  uint32_t state_off;  // index of the image's first entry in the chunk descriptor / state / sum / base arrays
   uint32_t n_blocks;   // coded blocks in the image: n_mcus * (ny + 2)
   uint32_t reserved;
 };
@@ -44,9 +46,18 @@ struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart int
   uint32_t first_interval;
 };
 
+constexpr uint32_t kJbLongInterval = 1024; // mean bytes per restart interval from which the chunk decoder is used for a file with DRI
 constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder
 constexpr int kJbSyncRounds = 16;        // synchronisation passes before the writing pass (which verifies): the default;
                                          // a lane whose start state did not change since the last pass skips its decode
+
+// Chunks never straddle a restart boundary: interval i is cut into chunks from its own first byte
+// (an empty interval still has one chunk, so that its missing blocks are noticed).
+inline uint32_t jb_chunks_of_(uint32_t interval_bytes) { return interval_bytes ? (interval_bytes + kJbChunkBytes - 1) / kJbChunkBytes : 1u; }
+struct JbChunkDesc {
+  uint32_t start;  // first byte of the chunk in the image's clean scan
+  uint32_t seg;    // the restart interval it lies in; bit 31: it is the interval's first chunk (its start state is known)
+};
 
 // Exit state of a chunk's decode: where the first symbol of the next chunk starts and in which state
 struct JbChunkState {
@@ -70,7 +81,9 @@ struct JbHuffLaunch {
   const uint32_t *sync_images; // ... and their indices (device)
   JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each: exit states of the passes, ping-pong
   JbChunkState *state_in;           // device scratch: the start state each chunk was last decoded from
-  uint32_t *base;              // device scratch: index of the block a chunk starts in
+  const JbChunkDesc *chunks;   // device: one descriptor per chunk
+  uint32_t *dcsum;             // device scratch, 4 words per chunk: sum of the DC differences decoded in the chunk, per component (Y, Cb, Cr, -)
+  uint32_t *base;              // device scratch, 4 words per chunk: index of the block the chunk starts in; DC predictors (Y, Cb, Cr) at its start
   int32_t sync_rounds;         // synchronisation passes (>= 1); n_chunks of them always suffice
 };
 
@@ -95,8 +108,10 @@ struct JbHuffJob {
   size_t scan_len = 0;           // clean bytes
   std::vector<uint32_t> starts;  // n_int + 1 entries
 };
-// JB_OK: the image is eligible and `job` is filled.  JB_ERR_UNSUPPORTED: a valid stream the device
-// decoder does not take (no restart intervals, markers that do not match the frame, more than two
+// JB_OK: the image is eligible and `job` is filled (img.n_chunks says which decoder: files without
+// DRI and files whose intervals average kJbLongInterval bytes or more take the chunk decoder;
+// JPEGBLK_HUFF_MODE=interval / chunk forces one for files with DRI).  JB_ERR_UNSUPPORTED: a valid stream the device
+// decoder does not take (markers that do not match the frame, more than two
 // DC or AC tables in use, a frame for the general front end) -- use the host decoder.  Other
 // negatives: the header errors of jb_entropy_decode.
 int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err);
@@ -110,11 +125,11 @@ struct JbHuffLayout {
   int64_t coef_stride = 0;
   // the self-synchronising decoder's part: its workgroup list and image list (uploaded), and the
   // device-only scratch behind the uploaded bytes (chunk states x 2, chunk bases)
-  size_t off_sync_wg = 0, off_sync_img = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_base = 0, device_total = 0;
+  size_t off_sync_wg = 0, off_sync_img = 0, off_chunks = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_dcsum = 0, off_base = 0, device_total = 0;
   int n_sync_wg = 0, n_sync_images = 0;
 };
-// Is the device decoder worth taking for this image?  Restart-interval mode: at least `min_intervals`
-// intervals; self-synchronising mode (no DRI): at least 16 chunks.
+// Is the device decoder worth taking for this image?  Interval decoder: at least `min_intervals`
+// intervals; self-synchronising decoder (no DRI, or long intervals): at least 16 chunks.
 inline bool jb_huff_worth_it_(const JbHuffJob &job, uint32_t min_intervals) {
   return job.img.n_chunks > 0 ? job.img.n_chunks >= 16u : job.img.n_int >= min_intervals;
 }

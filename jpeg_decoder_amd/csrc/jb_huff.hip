@@ -1,8 +1,9 @@
-// jb_huff.hip -- Huffman decoding of baseline scans ON THE DEVICE, one lane per restart interval
-// (gfx950).  Beyond the reference (its decodeHuffman, jpeg.cpp:405-446, is serial host code and
-// north_star keeps the entropy stage on the host): SURVEY.md section 8(f) rank 4.  Files with DRI
-// take the interval decoder below, files without the self-synchronising decoder further down;
-// progressive / grayscale / multi-scan files stay on the host (jb_frontend_ext.cpp).
+// jb_huff.hip -- Huffman decoding of baseline scans ON THE DEVICE (gfx950).  Beyond the reference
+// (its decodeHuffman, jpeg.cpp:405-446, is serial host code and north_star keeps the entropy stage
+// on the host): SURVEY.md section 8(f) rank 4.  Files with short restart intervals take the
+// interval decoder below (one lane per interval), files without DRI and files with long intervals
+// the self-synchronising decoder further down (one lane per 256-byte chunk); progressive /
+// grayscale / multi-scan files stay on the host (jb_frontend_ext.cpp).
 //
 // Why it works: the DC predictors reset at every restart marker (T.81 F.2.1.3.1; reference
 // jpeg.cpp:419-425), so the intervals of a scan are independent bit streams -- after the host has
@@ -290,31 +291,37 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
 }
 
 // ================================================================================================
-// Scans WITHOUT restart intervals: the self-synchronising decoder.
+// Scans WITHOUT restart intervals, and scans whose intervals are long: the self-synchronising decoder.
 //
 // A Huffman stream can only be decoded from its start -- but a decoder started at a wrong place,
 // in a wrong state, falls into step with the true symbol sequence after a few symbols or blocks
-// and stays in step from then on.  So the clean scan is cut into chunks of kJbChunkBytes bytes, one
-// lane per chunk:
+// and stays in step from then on.  So every restart interval (a scan without DRI is one interval)
+// is cut into chunks of kJbChunkBytes bytes from its own first byte, one lane per chunk -- a 1080p
+// file with one restart interval per MCU row is 3,000 lanes this way instead of the 135 of the
+// interval decoder above:
 //   sync pass 0      every lane decodes its chunk from the chunk's first bit, assuming "a DC symbol
-//                    of the MCU's first block is next", and records its EXIT state: the bit at
-//                    which the first symbol of the next chunk starts, the position k inside the
-//                    block, the block's place in the MCU, and how many blocks it completed;
+//                    of the MCU's first block is next" (true for the first chunk of an interval), and
+//                    records its EXIT state: the bit at which the first symbol of the next chunk
+//                    starts, the position k inside the block, the block's place in the MCU, how many
+//                    blocks it completed -- and the sum of the DC differences it decoded, per component;
 //   sync pass r > 0  every lane decodes its chunk again, now from the exit state its left neighbour
-//                    recorded in pass r - 1 (lane 0: from the true start).  Correct states spread
-//                    from the left, at least one chunk per pass, in practice across the whole scan
-//                    in a few passes because most lanes had fallen into step inside their own chunk
-//                    already.  A lane whose start state is the one it decoded from in the pass before
-//                    keeps its exit state and does nothing: passes after convergence cost a launch;
-//   scan             exclusive prefix sum of the blocks completed per chunk: the block each chunk starts in;
+//                    recorded in pass r - 1 (an interval's first chunk: from the true start).  Correct
+//                    states spread from the interval starts, at least one chunk per pass, in practice
+//                    across a whole scan in a few passes because most lanes had fallen into step inside
+//                    their own chunk already.  A lane whose start state is the one it decoded from in the
+//                    pass before keeps its results and does nothing: passes after convergence cost a launch;
+//   scan             exclusive prefix sums over the chunks of each interval: the block a chunk starts
+//                    in (an interval's first block is known: interval x ri x blocks per MCU) and the
+//                    three DC predictors at its start (0 at an interval's start: T.81 F.2.1.3.1;
+//                    reference jpeg.cpp:419-425);
 //   write pass       every lane decodes its chunk once more from its neighbour's final exit state
-//                    and this time stores the coefficients (DC as differences) -- and VERIFIES that
-//                    it ends in the exit state recorded for it: if every lane does, the chain from the
-//                    true start is consistent, i.e. this is the one true decode; if not (not yet
-//                    synchronised after kJbSyncRounds passes, or corrupt data) the image's status
-//                    word is set and the host decodes that image;
-//   DC pass          per component, the running sum of the DC differences (T.81 F.2.1.3.1; reference
-//                    jpeg.cpp:335-345) over the component's blocks in decode order.
+//                    and this time stores the coefficients, the DC ones as running predictors
+//                    (reference jpeg.cpp:335-345) -- and VERIFIES that it ends in the exit state
+//                    recorded for it, an interval's last chunk that it ends with the interval's last
+//                    block: if every lane does, the chain from every true start is consistent, i.e.
+//                    this is the one true decode; if not (not yet synchronised after kJbSyncRounds
+//                    passes, or corrupt data) the image's status word is set and the host decodes
+//                    that image.
 // A step is the same as in the interval decoder above; the tables, the stream ring and the layout
 // of the output are shared.  (Idea: Klein & Wiseman 2003; Weissenberger & Schmidt 2018 for JPEG on GPUs.)
 
@@ -322,10 +329,11 @@ namespace {
 
 struct ChunkLane {
   uint32_t k, blk, nblk;  // position in the block (0 = DC next), block within the MCU, blocks completed
+  uint32_t dc0, dc1, dc2; // sync passes: sum of the DC differences so far; write pass: the DC predictors
 };
 
-// one symbol; stores == false: only the state moves.  Returns false when the data cannot be what
-// the state says (the caller decides what that means).
+// one symbol; kStore == false: only the state moves (and the DC differences are summed).  Returns
+// false when the data cannot be what the state says (the caller decides what that means).
 template <bool kStore>
 __device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, const uint8_t *zz, uint32_t slots, uint32_t ny, uint32_t nb,
                                            ChunkLane &st, int16_t *block_out) {
@@ -340,10 +348,18 @@ __device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, con
   const bool eob = !isdc && rs == 0;
   const uint32_t kk = st.k + (isdc ? 0u : rs == 0xf0u ? 16u : (rs >> 4));
   if (e == 0 || (isdc ? sz > 11 : (!eob && (kk > 63 || sz > 10)))) return false;
-  if (kStore && sz) {
-    const int val = extend((bits << len) >> (32 - sz), (int)sz);  // (a DC symbol: the difference; the DC pass sums them)
-    JBH_STORE(block_out[zz[kk & 63]], (int16_t)val);
+  int val = 0;
+  if ((kStore || isdc) && sz) val = extend((bits << len) >> (32 - sz), (int)sz);
+  if (isdc) {
+    // (unsigned: the sums of a lane that is out of step are garbage and may wrap)
+    const uint32_t pr = (c == 0 ? st.dc0 : c == 1 ? st.dc1 : st.dc2) + (uint32_t)val;
+    if (kStore && ((int32_t)pr < -32768 || (int32_t)pr > 32767)) return false;  // a predictor the reference's short cannot hold
+    if (c == 0) st.dc0 = pr;
+    else if (c == 1) st.dc1 = pr;
+    else st.dc2 = pr;
+    val = (int32_t)pr;
   }
+  if (kStore && (isdc ? val != 0 : sz != 0)) JBH_STORE(block_out[zz[kk & 63]], (int16_t)val);
   s.consume(len + sz);
   st.k = isdc ? 1u : eob ? 64u : kk + (sz ? 1u : 0u);
   if (st.k > 63) {
@@ -357,6 +373,27 @@ __device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, con
 __device__ __forceinline__ void open_at_bit(Stream &s, uint32_t bit) {
   s.open(bit >> 3);
   s.off += bit & 7u;  // (start & 3) * 8 + (bit & 7) <= 31
+}
+
+// where a lane's chunk lies
+struct ChunkExtent {
+  uint32_t start_bit, end_bit;  // the chunk's bits in the image's clean scan (end: the interval's end at the latest)
+  uint32_t seg;                 // its restart interval
+  bool first, last;             // of its interval
+};
+__device__ __forceinline__ ChunkExtent chunk_extent(const JbHuffLaunch &p, const JbHuffImage &img, uint32_t ci) {
+  const JbChunkDesc cd = p.chunks[img.state_off + ci];
+  ChunkExtent x;
+  x.seg = cd.seg & 0x7fffffffu;
+  x.first = (cd.seg >> 31) != 0;
+  uint32_t seg_end = p.starts[img.int_off + x.seg + 1];
+  if (seg_end > img.scan_len) seg_end = img.scan_len;
+  uint32_t start = cd.start < seg_end ? cd.start : seg_end;
+  uint32_t end = start + kJbChunkBytes < seg_end ? start + kJbChunkBytes : seg_end;
+  x.last = end == seg_end;
+  x.start_bit = start * 8u;
+  x.end_bit = end * 8u;
+  return x;
 }
 
 }  // namespace
@@ -381,20 +418,17 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const uint32_t ci = wg.first_interval + (uint32_t)tid;  // this lane's chunk
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
-  const uint32_t total_bits = img.scan_len * 8u;
-  uint32_t bit = 0;
-  ChunkLane st{0, 0, 0};
-  bool skip = false;  // the start state is the one this chunk was decoded from last time: same exit state
+  uint32_t bit = 0, end_bit = 0;
+  ChunkLane st{0, 0, 0, 0, 0, 0};
+  bool skip = false;  // the start state is the one this chunk was decoded from last time: same results
   if (active) {
-    JbChunkState in{0, 0};
-    if (ci > 0) {
-      if (round == 0) {
-        in.bitpos = ci * (kJbChunkBytes * 8u);
-      } else {
-        const JbChunkState prev = src[img.state_off + ci - 1];
-        in.bitpos = prev.bitpos;
-        in.meta = prev.meta & 0xffffu;  // k and the block's place in the MCU
-      }
+    const ChunkExtent x = chunk_extent(p, img, ci);
+    end_bit = x.end_bit;
+    JbChunkState in{x.start_bit, 0};
+    if (!x.first && round > 0) {
+      const JbChunkState prev = src[img.state_off + ci - 1];
+      in.bitpos = prev.bitpos;
+      in.meta = prev.meta & 0xffffu;  // k and the block's place in the MCU
     }
     if (round > 0) {
       const JbChunkState last = p.state_in[img.state_off + ci];
@@ -405,10 +439,10 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     bit = in.bitpos;
     st.k = in.meta & 0xffu;
     st.blk = (in.meta >> 8) & 0xffu;
+    if (st.k > 63) st.k = 0;
+    if (st.blk >= nb) st.blk = 0;
   }
-  uint32_t end_bit = (ci + 1) * (kJbChunkBytes * 8u);
-  if (end_bit > total_bits) end_bit = total_bits;
-  if (bit > total_bits) bit = total_bits;
+  if (bit > end_bit) bit = end_bit;
   Stream s;
   s.base = p.scan + img.scan_off;
   s.limit = (img.scan_len + 48u) & ~15u;
@@ -430,32 +464,60 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       live = (uint32_t)s.bitpos() < end_bit;
     }
   }
-  if (active && !skip) dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
+  if (active && !skip) {
+    dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
+    *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(st.dc0, st.dc1, st.dc2, 0u);
+  }
 }
 
-// exclusive prefix sum of the blocks completed per chunk: one workgroup per image
+// exclusive prefix sums over the chunks of each interval -- blocks completed, DC differences per
+// component -- restarting at every interval's first chunk: one workgroup per image
 __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_scan_kernel(const JbHuffLaunch p, const JbChunkState *fin) {
-  __shared__ uint32_t part[kJbHuffLanes];
+  __shared__ uint4 part[kJbHuffLanes];
+  __shared__ uint32_t restarted[kJbHuffLanes];
   const JbHuffImage img = p.images[p.sync_images[blockIdx.x]];
   const uint32_t n = img.n_chunks, per = (n + kJbHuffLanes - 1) / kJbHuffLanes;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; i++) sum += fin[img.state_off + i].meta >> 16;
-  part[threadIdx.x] = sum;
+  const uint32_t lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+  const uint32_t blocks_per_interval = img.ri * (img.ny + 2);
+  const uint4 *sums = (const uint4 *)p.dcsum;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  uint32_t any = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t sg = p.chunks[img.state_off + i].seg;
+    if (sg >> 31) {
+      acc = make_uint4((sg & 0x7fffffffu) * blocks_per_interval, 0, 0, 0);
+      any = 1;
+    }
+    const uint4 d = sums[img.state_off + i];
+    acc.x += fin[img.state_off + i].meta >> 16;
+    acc.y += d.x;
+    acc.z += d.y;
+    acc.w += d.z;
+  }
+  part[threadIdx.x] = acc;
+  restarted[threadIdx.x] = any;
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t run = 0;
+    uint4 run = make_uint4(0, 0, 0, 0);
     for (int i = 0; i < kJbHuffLanes; i++) {
-      const uint32_t v = part[i];
+      const uint4 v = part[i];
       part[i] = run;
-      run += v;
+      if (restarted[i]) run = v;  // (v is absolute from the last interval start in lane i's range on)
+      else run = make_uint4(run.x + v.x, run.y + v.y, run.z + v.z, run.w + v.w);
     }
   }
   __syncthreads();
-  uint32_t run = part[threadIdx.x];
+  acc = part[threadIdx.x];
+  uint4 *base = (uint4 *)p.base;
   for (uint32_t i = lo; i < hi; i++) {
-    p.base[img.state_off + i] = run;
-    run += fin[img.state_off + i].meta >> 16;
+    const uint32_t sg = p.chunks[img.state_off + i].seg;
+    if (sg >> 31) acc = make_uint4((sg & 0x7fffffffu) * blocks_per_interval, 0, 0, 0);
+    base[img.state_off + i] = acc;
+    const uint4 d = sums[img.state_off + i];
+    acc.x += fin[img.state_off + i].meta >> 16;
+    acc.y += d.x;
+    acc.z += d.y;
+    acc.w += d.z;
   }
 }
 
@@ -479,23 +541,35 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   const uint32_t ci = wg.first_interval + (uint32_t)tid;
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
-  const uint32_t total_bits = img.scan_len * 8u;
-  uint32_t bit = 0, block = 0;
-  ChunkLane st{0, 0, 0};
+  uint32_t bit = 0, end_bit = 0, block = 0, block_end = 0;
+  bool last = false;
+  ChunkLane st{0, 0, 0, 0, 0, 0};
   JbChunkState want{0, 0};
   if (active) {
+    const ChunkExtent x = chunk_extent(p, img, ci);
+    end_bit = x.end_bit;
+    last = x.last;
+    bit = x.start_bit;
     want = fin[img.state_off + ci];
-    block = p.base[img.state_off + ci];
-    if (ci > 0) {
+    const uint4 b = ((const uint4 *)p.base)[img.state_off + ci];
+    block = b.x;
+    st.dc0 = b.y;
+    st.dc1 = b.z;
+    st.dc2 = b.w;
+    // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
+    const uint32_t m1 = (x.seg + 1) * img.ri < img.n_mcus ? (x.seg + 1) * img.ri : img.n_mcus;
+    block_end = m1 * nb;
+    if (!x.first) {
       const JbChunkState prev = fin[img.state_off + ci - 1];
       bit = prev.bitpos;
       st.k = prev.meta & 0xffu;
       st.blk = (prev.meta >> 8) & 0xffu;
+      if (st.k > 63) st.k = 0;
+      if (st.blk >= nb) st.blk = 0;
     }
   }
-  uint32_t end_bit = (ci + 1) * (kJbChunkBytes * 8u);
-  if (end_bit > total_bits) end_bit = total_bits;
-  if (bit > total_bits) bit = total_bits;
+  if (bit > end_bit) bit = end_bit;
+  if (block_end > img.n_blocks) block_end = img.n_blocks;  // (the output is sized for n_blocks)
   Stream s;
   s.base = p.scan + img.scan_off;
   s.limit = (img.scan_len + 48u) & ~15u;
@@ -503,73 +577,29 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   open_at_bit(s, active ? bit : 0u);
   int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
   uint32_t err = 0;
-  // (block < n_blocks: the padding bits behind the image's last block are not symbols)
-  bool live = active && bit < end_bit && block < img.n_blocks;
+  bool live = active && bit < end_bit && block < block_end;
   for (uint32_t step = 0;; step++) {
     if ((step & 3u) == 0) {
       if (__builtin_amdgcn_ballot_w64(live) == 0) break;
       if (live) s.top_up();
     }
     if (live) {
-      const uint32_t before = st.nblk;
       if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, coef + (int64_t)(block + st.nblk) * 64)) {
         err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
         live = false;
       } else {
-        (void)before;
-        live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < img.n_blocks;
+        live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < block_end;
       }
     }
   }
   if (active) {
-    const bool last = ci + 1 == img.n_chunks;
     if (last) {
-      if (block + st.nblk != img.n_blocks || st.k != 0) err |= 2;  // the scan ends before the frame does
+      if (block + st.nblk != block_end || st.k != 0) err |= 2;  // the interval's data ends before its blocks do
     } else if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta) {
       err |= 4;  // this chunk does not end where the synchronisation passes said it would
     }
     if (err) atomicOr(p.status + wg.image, err);
   }
-}
-
-// the DC pass: blocks hold DC differences; per component, turn them into the running predictor
-// (grid: 3 workgroups per image of the sync list)
-__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_dc_kernel(const JbHuffLaunch p) {
-  __shared__ int32_t part[kJbHuffLanes];
-  const uint32_t which = blockIdx.x / 3, c = blockIdx.x % 3;
-  const uint32_t image = p.sync_images[which];
-  const JbHuffImage img = p.images[image];
-  const uint32_t nb = img.ny + 2, n_mcus = img.n_blocks / nb;
-  const uint32_t n = c == 0 ? n_mcus * img.ny : n_mcus;  // blocks of this component
-  int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
-  auto at = [&](uint32_t j) -> int16_t * {  // DC coefficient of the component's j-th block in decode order
-    const uint32_t b = c == 0 ? (j / img.ny) * nb + j % img.ny : j * nb + img.ny + (c - 1);
-    return coef + (int64_t)b * 64;
-  };
-  const uint32_t per = (n + kJbHuffLanes - 1) / kJbHuffLanes;
-  const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-  int32_t sum = 0;
-  for (uint32_t j = lo; j < hi; j++) sum += *at(j);
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int32_t run = 0;
-    for (int i = 0; i < kJbHuffLanes; i++) {
-      const int32_t v = part[i];
-      part[i] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  int32_t run = part[threadIdx.x];
-  bool bad = false;
-  for (uint32_t j = lo; j < hi; j++) {
-    int16_t *d = at(j);
-    run += *d;
-    bad |= run < -32768 || run > 32767;
-    *d = (int16_t)run;
-  }
-  if (bad) atomicOr(p.status + image, 1u);
 }
 
 hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
@@ -587,7 +617,6 @@ hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
     }
     hipLaunchKernelGGL(jb_huff_scan_kernel, dim3((unsigned)p.n_sync_images), block, 0, stream, p, fin);
     hipLaunchKernelGGL(jb_huff_write_kernel, grid, block, 0, stream, p, fin);
-    hipLaunchKernelGGL(jb_huff_dc_kernel, dim3((unsigned)p.n_sync_images * 3u), block, 0, stream, p);
   }
   return hipGetLastError();
 }

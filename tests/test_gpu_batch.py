@@ -209,3 +209,48 @@ def test_batch_decoder_device_entropy_falls_back_per_image(jb, oracle, tmp_path,
             assert (st[i] == 0) == host_accepts
         else:
             assert st[i] == 0 and np.array_equal(imgs[i], want[i]), i
+
+
+@pytest.mark.parametrize("entropy", ["host", "device"])
+def test_batch_decoder_headers_beyond_the_head_read_in_pass_1(jb, tmp_path, monkeypatch, entropy):
+    """Pass 1 of the batch decoder reads only the first 64 KB of a file to size its buffers; a file
+    whose tables and frame header come later (here: 3 x 60 KB of APPn / COM segments in front of
+    them, as a camera file with a thumbnail and a colour profile has), a file that ends inside that
+    padding and a progressive file must come out exactly as from the single-image decode of the whole
+    file."""
+    from conftest import BASELINE_IMAGES, GOLD, load_golden
+    if entropy == "host":
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    paths, want = [], []
+    pad = b"".join(bytes([0xff, m, 0xea, 0x62]) + bytes(60000) for m in (0xe1, 0xe2, 0xfe))  # length 0xea62 = 60002
+    for n in BASELINE_IMAGES:
+        raw = open(os.path.join(GOLD, "images", n + ".jpg"), "rb").read()
+        assert raw[:2] == b"\xff\xd8"
+        for tag, data in (("plain", raw), ("padded", raw[:2] + pad + raw[2:])):
+            p = str(tmp_path / f"{n}_{tag}.jpg")
+            open(p, "wb").write(data)
+            paths.append(p)
+            want.append(load_golden(n)[3])
+    cut = str(tmp_path / "cut.jpg")
+    open(cut, "wb").write(open(paths[1], "rb").read()[:70000])  # ends inside the padding
+    prog = os.path.join(GOLD, "images", "prograssive-sample-2.jpg")
+    extra = [cut] + ([prog] if os.path.exists(prog) else [])
+    with jb.Context(0) as one:
+        singles = []
+        for p in extra:
+            try:
+                singles.append(one.decode_file(p))
+            except jb.JbError as e:
+                singles.append(e.status)
+    with jb.BatchDecoder(4, 0) as dec:
+        imgs, st, tm = dec.run(paths + extra)
+    for i, w in enumerate(want):
+        assert st[i] == 0 and np.array_equal(imgs[i], w), (i, paths[i], st[i])
+    for j, s in enumerate(singles):
+        i = len(paths) + j
+        if isinstance(s, int):
+            assert st[i] == s and imgs[i] is None, (extra[j], st[i], s)
+        else:
+            assert st[i] == 0 and np.array_equal(imgs[i], s), extra[j]

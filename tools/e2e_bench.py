@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
                     "the batch decoder decodes the entropy stage on the device by default, JPEGBLK_GPU_HUFFMAN=0 on the host threads")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip part (2), so that the last device activity of the run is the last "
+                    "timed batch (tools/timeline.py reads that burst out of a rocprofv3 trace)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -176,6 +178,9 @@ def main():
             if rank == 0:
                 print(json.dumps(out))
             dist.destroy_process_group()
+            return
+        if args.no_pcie:
+            print(json.dumps(out))
             return
         # (2) PCIe-inclusive block pipeline from pre-decoded coefficients
         desc, q, coef = jb.entropy_decode(open(distinct[0], "rb").read())

@@ -74,6 +74,8 @@ def main():
             _, _, cd = ctx.entropy_decode_device(bytes(s))
             assert np.array_equal(cd, jb.entropy_decode(bytes(s))[2])
         while time.time() - t0 < args.seconds:
+            # files with restart intervals: either device decoder (jb_huff_prepare_ reads the knob per image)
+            os.environ["JPEGBLK_HUFF_MODE"] = ("interval", "chunk")[int(rng.integers(0, 2))]
             data = mutate(rng, base[int(rng.integers(0, len(base)))])
             try:
                 _, _, cd = ctx.entropy_decode_device(data)
@@ -91,7 +93,8 @@ def main():
                     assert np.array_equal(cd, ch), "device and host decoders disagree on a stream both accept"
                     agree += 1
     total = sum(counts.values())
-    print(f"huff fuzz ok: {total} mutants, statuses {dict(sorted(counts.items()))}, {agree} accepted by both decoders and equal")
+    os.environ.pop("JPEGBLK_HUFF_MODE", None)
+    print(f"huff fuzz ok (files with DRI through either device decoder at random): {total} mutants, statuses {dict(sorted(counts.items()))}, {agree} accepted by both decoders and equal")
 
 
 if __name__ == "__main__":

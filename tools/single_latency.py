@@ -53,19 +53,26 @@ def timed(ctx, data, reps):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="WxH: just this size (for a kernel trace)")
+    ap.add_argument("--dri", default="0,1", help="restart interval in MCU rows, comma separated (0 = none)")
+    args = ap.parse_args()
     sizes = [(679, 451, "420"), (1920, 1080, "444"), (1920, 1080, "420"), (4096, 4096, "420"), (4096, 4096, "444"), (8192, 8192, "420")]
+    if args.only:
+        sizes = [x for x in sizes if f"{x[0]}x{x[1]}" == args.only]
     rows = []
     with jb.Context(0) as ctx:
         for w, h, sub in sizes:
-            for dri in (0, 1):
+            for dri in [int(v) for v in args.dri.split(",")]:
                 src, data = make(w, h, sub, dri)
                 reps = 8 if w * h < 3e7 else 4
                 os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
                 t_host, ref = timed(ctx, data, reps)
                 os.environ["JPEGBLK_GPU_HUFFMAN"] = "2"
-                before = ctx.device_entropy_images()
+                before = ctx.device_entropy_images
                 t_dev, px = timed(ctx, data, reps)
-                took = ctx.device_entropy_images() - before
+                took = ctx.device_entropy_images - before
                 same = bool(np.array_equal(ref, px))
                 row = {"size": f"{w}x{h}", "sub": sub, "dri_rows": dri, "source": src, "bytes": len(data),
                        "host_ms": round(t_host * 1e3, 3), "device_ms": round(t_dev * 1e3, 3),
