@@ -26,6 +26,13 @@ Prints ONE JSON line on rank 0:  metric = Mpixels/s decoded (whole job), plus
                launch, both COLD (rotating buffer sets totalling > 512 MiB, twice the Infinity
                Cache), HIP events around every launch, median of >= 200; plus the per-GPU shares
                of the batch configs and the reference's bundled-image size;
+  end_to_end   decode(path) over batches of synthetic JPEG FILES (written by the build's own baseline
+               writer): BASELINE.json configs 4 and 5 weak-scaled like the headline -- every rank
+               decodes one GPU's share at 8 GPUs (128 x 1920x1080 4:4:4, 32 x 8192x8192 4:2:0)
+               through jb_batch_decoder: parse + byte de-stuffing on the host threads, Huffman
+               decoding + IDCT + colour on the device, pixels into pinned host memory (PCIe-
+               inclusive, so never `value`); images/s = all ranks' images / the slowest rank's wall;
+               at N=1 also with the entropy stage on the host threads (north_star's split);
   cpu_baseline the reference CPU path (oracle/_ref, the genuine reference compiled in place,
                kind "reference") or, if that build is absent, the C restatement (kind "port"),
                timed on this box's host cores on a bounded sample -- rank 0, N=1 only.
@@ -133,6 +140,76 @@ def fan_out(n_gpus, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+# (key, workload, files per GPU, restart interval in MCU rows, what it is): BASELINE.json's batch
+# configurations as files on disk, one GPU's share at 8 GPUs per rank
+E2E_CONFIGS = [
+    ("config4_files_1080p_444", "1920x1080-444", 128, 0, "BASELINE config 4: 1024 x 1920x1080 4:4:4 JPEG files over 8 GPUs = 128 per GPU"),
+    ("config5_files_8192_420", "8192x8192-420", 32, 0, "BASELINE config 5: 256 x 8192x8192 4:2:0 JPEG files over 8 GPUs = 32 per GPU"),
+]
+
+
+def end_to_end(jb, np, dist, dev_index, reduce_device, rank, world, tmpdir):
+    """decode(path) over batches of files, every rank its own share; -> dict (identical on all ranks)."""
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.shard import job_throughput
+    threads = max(2, min(16, len(os.sched_getaffinity(0)) // world))  # (the library caps it by the cgroup CPU quota as well)
+    out = {"what": "jb_batch_decoder over JPEG files on local disk (page cache): parse + de-stuffing on the host threads, "
+                   "entropy decoding + IDCT + colour on the device, pixels into a pinned host arena; weak-scaled: files per GPU fixed",
+           "host_threads_per_gpu": threads, "files": "synthetic blocks through tools/jpegwriter (Annex-K tables, quality-75 tables), 2 distinct per size, the rest MCU rotations",
+           "runs": {}}
+    for key, wl, per_gpu, ri_rows, what in E2E_CONFIGS:
+        w, h, hs, vs = parse_workload(wl)
+        coef, q = synth.synth_blocks(w, h, hs, vs, image_index=7)
+        bpm = hs * vs + 2
+        mcus_x = (w + 8 * hs - 1) // (8 * hs)
+        paths = []
+        for i in range(2):
+            path = os.path.join(tmpdir, f"{key}_{i}.jpg")
+            with open(path, "wb") as f:
+                f.write(synth.encode_jpeg(np.roll(coef, i * 4099 * bpm, axis=0), w, h, hs, vs, q, restart_interval=ri_rows * mcus_x))
+            paths.append(path)
+        del coef
+        files = [paths[i % 2] for i in range(per_gpu)]
+        with jb.Context(dev_index) as one:
+            want = [one.decode_file(p) for p in paths]
+        g = jb.geometry_of(jb.make_desc(w, h, hs, vs))
+        res = {"what": what, "workload": wl, "files_per_gpu": per_gpu, "file_bytes": os.path.getsize(paths[0])}
+        modes = [("device", None)] + ([("host", "0")] if world == 1 else [])
+        for label, knob in modes:
+            if knob is None:
+                os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+            else:
+                os.environ["JPEGBLK_GPU_HUFFMAN"] = knob
+            arena = per_gpu * ((g.rgb_bytes + 255) // 256 * 256)
+            bad = []
+
+            def check(i, view):
+                if i < 4 and not np.array_equal(view, want[i % 2]):
+                    bad.append(i)
+
+            with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes, arena_bytes=arena) as dec:
+                dec.run(files[:threads], keep_pixels=False)
+                walls = []
+                for k in range(3):
+                    if dist is not None:
+                        dist.barrier()
+                    _, st, tm = dec.run(files, keep_pixels=False, on_image=check if k == 0 else None)
+                    if any(x != 0 for x in st) or bad:
+                        raise RuntimeError(f"end_to_end {key}: statuses {sorted(set(st))}, images that differ from the single-image decode: {bad}")
+                    n_all, wall = job_throughput(dist, reduce_device, per_gpu, tm["wall_s"])
+                    walls.append(wall)
+                on_device = dec.device_entropy_images > 0
+            best = min(walls)
+            res[f"entropy_on_{label}"] = {"images_per_s": round(n_all / best, 1), "mpix_s": round(n_all * w * h / best / 1e6, 1),
+                                           "wall_s": round(best, 4), "walls": [round(x, 4) for x in walls], "images": int(n_all),
+                                           "entropy_stage_ran_on_device": bool(on_device), "pixels_checked_per_rank": 4}
+        os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+        out["runs"][key] = res
+        for p_ in paths:
+            os.remove(p_)
+    return out
+
+
 class Resident:
     """`sets` buffer sets of `nimg` images each, resident in HBM, plus the launch descriptors."""
 
@@ -171,6 +248,7 @@ def main():
                     help="untimed launches before the warm-up steps (lets clocks/power settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra per-config measurements (N=1)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the decode(path) batches over JPEG files (configs 4 and 5 end to end)")
     ap.add_argument("--images-per-step", type=int, default=IMAGES_PER_STEP)
     ap.add_argument("--sets", type=int, default=1, help="rotating buffer sets (cold single-image runs: > 512 MiB in total)")
     ap.add_argument("--workload", default="4096x4096-444",
@@ -286,6 +364,12 @@ def main():
     del head
     torch.cuda.empty_cache()
 
+    e2e = None
+    if not args.no_e2e:
+        import tempfile
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmpdir:
+            e2e = end_to_end(jb, np, dist, local_rank, dev if backend == "nccl" else torch.device("cpu"), rank, world, tmpdir)
+
     if rank == 0:
         traffic, traffic_note = None, "no profiles/pmc_latest.json"
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -337,6 +421,8 @@ def main():
                 del res
                 torch.cuda.empty_cache()
             line["configs"] = cfgs
+        if e2e is not None:
+            line["end_to_end"] = e2e
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(WIDTH, HEIGHT, HS, VS, head_coef, head_q)
         print(json.dumps(line), flush=True)

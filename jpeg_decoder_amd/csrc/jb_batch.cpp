@@ -22,11 +22,11 @@
 #include <vector>
 
 #include <sched.h>
-#include <sys/mman.h>
 
 #include <memory>
 
 #include "../../include/jpegblk.h"
+#include "jb_hostmem.h"
 #include "jb_huff.h"
 
 struct jb_ctx;
@@ -78,18 +78,6 @@ bool read_prefix(const char *path, size_t limit, std::vector<uint8_t> &buf, bool
   *whole = got <= limit;
   buf.resize(got < limit ? got : (*whole ? got : limit));
   return true;
-}
-
-// A caller-owned pixel buffer (released with jb_free = free).  Large images are first-touched by
-// the copy out of the pinned staging: with 4 KiB pages that is 49,000 page faults for one
-// 8192x8192 image, taken by 16 threads at once, so ask for transparent huge pages.
-uint8_t *alloc_pixels(size_t bytes) {
-  constexpr size_t kHuge = (size_t)2 << 20;
-  if (bytes < 2 * kHuge) return (uint8_t *)malloc(bytes);
-  void *p = nullptr;
-  if (posix_memalign(&p, kHuge, (bytes + kHuge - 1) & ~(kHuge - 1)) != 0) return nullptr;
-  madvise(p, (bytes + kHuge - 1) & ~(kHuge - 1), MADV_HUGEPAGE);  // advisory: ignoring a failure is fine
-  return (uint8_t *)p;
 }
 
 // CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota
@@ -505,7 +493,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       r.heights[i] = p.desc.height;
       r.rgb[i] = nullptr;
       if (st == JB_OK) {
-        r.rgb[i] = use_arena ? dst + (size_t)j * rgb_bytes : alloc_pixels(rgb_bytes);
+        r.rgb[i] = use_arena ? dst + (size_t)j * rgb_bytes : jb_alloc_pixels_(rgb_bytes);
         if (!r.rgb[i]) {
           st = JB_ERR_CAPACITY;
           text = "out of memory";

@@ -31,6 +31,7 @@
 
 #include "../../include/jpegblk.h"
 #include "jb_entropy.h"
+#include "jb_hostmem.h"
 #include "jb_huff.h"
 
 struct jb_ctx;
@@ -408,7 +409,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
       if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int) &&
           (forced || job->scan_len >= kAutoDeviceScan)) {
-        uint8_t *out = (uint8_t *)malloc((size_t)job->geo.rgb_bytes);
+        uint8_t *out = jb_alloc_pixels_((size_t)job->geo.rgb_bytes);
         if (!out) return jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
         const int rc = jb_decode_job_(ctx, job.get(), out, 3LL * job->desc.width);
         if (rc == JB_OK) {
@@ -439,7 +440,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   uint8_t *out = nullptr;
   if (rc) jb_fail_(ctx, rc, jb_last_error(nullptr));
   else {
-    out = (uint8_t *)malloc((size_t)g.rgb_bytes);
+    out = jb_alloc_pixels_((size_t)g.rgb_bytes);
     if (!out) rc = jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
     else rc = jb_blocks_to_rgb(ctx, &desc, coef, qtabs, out, 3LL * desc.width);
   }

@@ -408,13 +408,6 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const JbHuffImage img = p.images[wg.image];
   const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
                          ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
-  {
-    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
-    uint4 *dst4 = (uint4 *)&lds.t;
-    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
-    if (tid < 64) zz[tid] = kZigZagDev[tid];
-  }
-  __syncthreads();
   const uint32_t ci = wg.first_interval + (uint32_t)tid;  // this lane's chunk
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
@@ -442,6 +435,16 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     if (st.k > 63) st.k = 0;
     if (st.blk >= nb) st.blk = 0;
   }
+  // a workgroup whose chunks are all in step has nothing to decode: the passes after convergence
+  // cost a launch and these few loads, not 18 KiB of tables per workgroup
+  if (!__syncthreads_or(active && !skip)) return;
+  {
+    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
+    uint4 *dst4 = (uint4 *)&lds.t;
+    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
+    if (tid < 64) zz[tid] = kZigZagDev[tid];
+  }
+  __syncthreads();
   if (bit > end_bit) bit = end_bit;
   Stream s;
   s.base = p.scan + img.scan_off;

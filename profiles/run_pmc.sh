@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-e2e"
 rocprofv3 -L > $OUT/counters.txt 2>&1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \

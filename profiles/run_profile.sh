@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the default bench command (400 untimed pre-conditioning launches, 20 warm-up, 200 timed steps)
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-configs ${JB_BENCH_ARGS:-}"   # JB_BENCH_ARGS="--workload 4096x4096-420" profiles another config
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-configs --no-e2e ${JB_BENCH_ARGS:-}"   # JB_BENCH_ARGS="--workload 4096x4096-420" profiles another config
 TIMED=200
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"

@@ -13,7 +13,7 @@ run_one() {  # name, bench args, algorithmic bytes per launch
   local NAME=$1 ARGS=$2 ALG=$3
   local OUT=$R/gpurun_out/prof_${TAG}_$NAME
   mkdir -p $OUT
-  local BENCH="python3 $R/bench.py $COMMON $ARGS"
+  local BENCH="python3 $R/bench.py --no-e2e $COMMON $ARGS"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || echo "trace failed: $NAME"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed: $NAME"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $BENCH > $OUT/pmc_write.log 2>&1 || echo "pmc write failed: $NAME"

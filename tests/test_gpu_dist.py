@@ -69,3 +69,8 @@ def test_bench_gpus_2_run_plainly_reports_two_ranks():
     assert d["config"]["launched_by"] == "bench.py" and "x2" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d and "configs" not in d                   # N = 1 only
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    # configs 4 and 5 end to end over files: every rank decodes its share, the line counts all of them
+    runs = d["end_to_end"]["runs"]
+    assert runs["config4_files_1080p_444"]["entropy_on_device"]["images"] == 2 * 128
+    assert runs["config5_files_8192_420"]["entropy_on_device"]["images"] == 2 * 32
+    assert all(r["entropy_on_device"]["entropy_stage_ran_on_device"] and r["entropy_on_device"]["images_per_s"] > 0 for r in runs.values())

@@ -11,7 +11,7 @@ for rep in $(seq $REPS); do
     # workload[:images per launch[:rotating buffer sets]]
     IFS=: read -r wl n sets <<< "$w"; n=${n:-8}; sets=${sets:-1}
     for lib in $LIBS; do
-      JPEGBLK_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-configs --workload $wl --images-per-step $n --sets $sets ${AB_BENCH_ARGS:-} 2>/dev/null |
+      JPEGBLK_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-configs --no-e2e --workload $wl --images-per-step $n --sets $sets ${AB_BENCH_ARGS:-} 2>/dev/null |
         python3 -c "
 import sys, json
 for l in sys.stdin:

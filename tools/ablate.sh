@@ -14,7 +14,7 @@ if [ "${1:-}" = build ]; then
 fi
 for v in "" NO_LOAD NO_IDCT NO_COLOUR NO_MATH NO_STORE; do
   lib=$R/jpeg_decoder_amd/libjpegblk.so; [ -n "$v" ] && lib=$R/tools/ab/libjpegblk_$v.so
-  JPEGBLK_LIB=$lib timeout -k 10 200 python3 $R/bench.py --no-cpu-baseline ${JB_BENCH_ARGS:-} 2>/dev/null | python3 -c "
+  JPEGBLK_LIB=$lib timeout -k 10 200 python3 $R/bench.py --no-cpu-baseline --no-e2e ${JB_BENCH_ARGS:-} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
