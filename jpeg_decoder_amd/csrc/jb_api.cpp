@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -732,13 +733,20 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
 // decode(bytes) with the entropy stage on the device: one prepared image through the ring
 // (used by jb_decode_memory, jb_frontend.cpp); the staging ring follows the frame
 int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_stride) {
+  static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '1';
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = timing ? now() : 0;
   int rc = jb_ctx_reserve(ctx, (size_t)job->geo.coef_bytes, (size_t)job->geo.rgb_bytes);
   if (rc) return rc;
+  const double t1 = timing ? now() : 0;
   int ticket = -1;
   const JbHuffJob *jobs[1] = {job};
   rc = submit_jobs_impl(ctx, jobs, nullptr, nullptr, nullptr, nullptr, 1, rgb, rgb_stride, nullptr, &ticket);
   if (rc) return rc;
-  return jb_wait(ctx, ticket);
+  const double t2 = timing ? now() : 0;
+  rc = jb_wait(ctx, ticket);
+  if (timing) fprintf(stderr, "jb_decode_job_: reserve %.3f ms, pack + submit %.3f ms, wait %.3f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now() - t2) * 1e3);
+  return rc;
 }
 
 // several prepared images of ONE geometry in one submission (jb_batch.cpp); pixels contiguous, tight rows

@@ -21,6 +21,7 @@
 //  * restart intervals are counted in MCUs as ITU-T T.81 says; the reference's test
 //    (jpeg.cpp:414,419) agrees with that only when an interval is a whole number of MCU rows
 //    (true for its bundled images/img4.jpg: interval 100 = one row).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -406,12 +407,20 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
     const bool automatic = !knob || (knob[0] != '0' && !forced);
     const uint32_t min_int = (knob && knob[0] == '2') ? 1u : 16u;
     if (forced || (automatic && jpeg_bytes >= kAutoDeviceScan)) {
+      // JPEGBLK_TIMING=1: where one decode(bytes) through the device path spends its time, on stderr
+      static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '1';
+      auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      const double t0 = timing ? now() : 0;
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
       if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int) &&
           (forced || job->scan_len >= kAutoDeviceScan)) {
+        const double t1 = timing ? now() : 0;
         uint8_t *out = jb_alloc_pixels_((size_t)job->geo.rgb_bytes);
         if (!out) return jb_fail_(ctx, JB_ERR_CAPACITY, "out of host memory");
         const int rc = jb_decode_job_(ctx, job.get(), out, 3LL * job->desc.width);
+        if (timing)
+          fprintf(stderr, "jb_decode_memory(device path): prepare %.3f ms, submit + wait %.3f ms (%u intervals, %u chunks, %zu bytes of scan), rc %d\n",
+                  (t1 - t0) * 1e3, (now() - t1) * 1e3, job->img.n_int, job->img.n_chunks, job->scan_len, rc);
         if (rc == JB_OK) {
           *rgb = out;
           *width = job->desc.width;
