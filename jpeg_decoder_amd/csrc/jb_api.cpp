@@ -630,6 +630,9 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     if (rc) return fail(ctx, rc, "bad quantisation table id");
   }
   JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768u * (size_t)n_images, hipMemcpyHostToDevice, up));
+  static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '2';
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tt0 = timing ? now() : 0;
   JbHuffLayout lay_own;
   if (jobs) {
     rc = pack_into_slot(ctx, s, jobs, n_images, g.coef_bytes, &lay_own);
@@ -638,8 +641,12 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     lay_in = &lay_own;
   }
   if (lay_in->n != n_images || lay_in->coef_stride != g.coef_bytes) return fail(ctx, JB_ERR_STATE, "packed submission does not match its descriptor");
+  const double tt1 = timing ? now() : 0;
   rc = huff_stage(ctx, s, packed, *lay_in, coef_total, (int16_t *)s.d_coef, up);
   if (rc) return rc;
+  const double tt2 = timing ? now() : 0;
+  if (timing) (void)hipStreamSynchronize(up);
+  const double tt3 = timing ? now() : 0;
   jb_device_batch b;
   memset(&b, 0, sizeof b);
   b.desc = *desc;
@@ -665,8 +672,12 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   // the status words travel with the pixels: into the caller's (pinned) words when it keeps its own
   // -- many threads share this ring, a slot's words may be recycled before their owner looks -- else
   // into the slot's, which jb_wait / jb_poll check
+  const double tt4 = timing ? now() : 0;
   JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, down));
   JB_HIP(ctx, hipEventRecord(s.done, down));
+  if (timing)
+    fprintf(stderr, "submit (device entropy): pack %.3f ms, upload + launches issued %.3f ms, entropy kernels done after %.3f ms more, pixel kernel + download call %.3f ms\n",
+            (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, (tt4 - tt3) * 1e3);
   s.busy = true;
   ctx->n_device_entropy += n_images;
   s.n_status = status_out ? 0 : n_images;

@@ -120,17 +120,29 @@ struct Parsed {
   std::string error;
 };
 
-constexpr int kSlots = 2;      // pinned buffers per host thread: decode image k while k-1 is in flight
+constexpr int kMaxSlots = 4;
+// pinned buffers per host thread = its submissions in flight: decode group k while k-1 .. k-n+1 are on the device.
+// Two: three or four (JPEGBLK_LANE_SLOTS, A/B knob), smaller groups, and first groups of different sizes per
+// thread (so that the threads' groups do not travel in lock-step) were measured on 1,024 1080p and 64
+// 8192x8192 files and stayed inside the run-to-run spread (profiles/r02b/ab_pipeline_depth.txt)
+int lane_slots() {
+  static const int n = [] {
+    const char *e = getenv("JPEGBLK_LANE_SLOTS");
+    const int v = e ? atoi(e) : 2;
+    return v < 2 ? 2 : v > kMaxSlots ? kMaxSlots : v;
+  }();
+  return n;
+}
 
 // what one host thread owns across runs: the pinned buffers its Huffman stage decodes into and,
 // when the caller's pixel buffers are pageable (no arena), pinned pixel staging -- a
 // device-to-host copy into pageable memory would block the device thread until the kernel has run
 struct Lane {
-  int16_t *coef[kSlots] = {nullptr, nullptr};
-  uint8_t *out[kSlots] = {nullptr, nullptr};
-  uint32_t *status[kSlots] = {nullptr, nullptr};  // per image of a group decoded on the device: its status word
-  uint8_t *blob[kSlots] = {nullptr, nullptr};     // pinned: a device-entropy group packed for upload (jb_huff_pack_)
-  size_t blob_cap[kSlots] = {0, 0};
+  int16_t *coef[kMaxSlots] = {};
+  uint8_t *out[kMaxSlots] = {};
+  uint32_t *status[kMaxSlots] = {};  // per image of a group decoded on the device: its status word
+  uint8_t *blob[kMaxSlots] = {};     // pinned: a device-entropy group packed for upload (jb_huff_pack_)
+  size_t blob_cap[kMaxSlots] = {};
   int device_of_blobs = 0;
   uint8_t *ensure_blob(int device, int s, size_t need) {
     if (need <= blob_cap[s]) return blob[s];
@@ -152,7 +164,7 @@ struct Lane {
     if (need_rgb < cap_rgb) need_rgb = cap_rgb;
     release();
     int rc = JB_OK;
-    for (int s = 0; s < kSlots && rc == JB_OK; s++) {
+    for (int s = 0; s < lane_slots() && rc == JB_OK; s++) {
       coef[s] = (int16_t *)jb_pinned_alloc_on(device, need_coef);
       if (!coef[s]) rc = JB_ERR_HIP;
       if (rc == JB_OK && !status[s]) {
@@ -174,14 +186,14 @@ struct Lane {
     return rc;
   }
   void drop_out() {
-    for (int s = 0; s < kSlots; s++) {
+    for (int s = 0; s < kMaxSlots; s++) {
       jb_pinned_free(out[s]);
       out[s] = nullptr;
     }
     has_out = false;
   }
   void release() {
-    for (int s = 0; s < kSlots; s++) {
+    for (int s = 0; s < kMaxSlots; s++) {
       jb_pinned_free(coef[s]);
       coef[s] = nullptr;
       jb_pinned_free(status[s]);
@@ -315,7 +327,8 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   struct Group {
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
     bool on_device = false;              // the group's entropy stage ran on the device (jb_huff.hip)
-  } grp[kSlots];
+  } grp[kMaxSlots];
+  const int kSlots = lane_slots();
   // Where the entropy stage runs.  The batch decoder's default is the DEVICE for every baseline image
   // the device decoders take (restart intervals: one lane per interval; none: the self-synchronising
   // decoder), 16 intervals / chunks or more: measured against 16 host threads it is 1.06x (8,192 small
@@ -563,10 +576,10 @@ struct jb_batch_decoder {
     jb_ctx_destroy(ctx);
     ctx = nullptr;
     ctx_coef = ctx_rgb = 0;
-    // ring depth = everything the host threads can have in flight (kSlots images each), so that a
+    // ring depth = everything the host threads can have in flight (lane_slots() submissions each), so that a
     // submission never blocks a thread that could be decoding; device memory is not the scarce
     // resource here (32 slots of 8192x8192 4:2:0 are 13 GB of 288)
-    int ring = kSlots * (int)lanes.size();
+    int ring = lane_slots() * (int)lanes.size();
     if (ring > 64) ring = 64;
     int rc = jb_ctx_create(device, need_coef, need_rgb, ring, &ctx);
     if (rc == JB_OK) {
