@@ -156,6 +156,22 @@ hipError_t build_ring(jb_ctx *ctx) {
   return e;
 }
 
+// The ring slot of the next submission: strict round robin; a full ring blocks the submitter on the
+// oldest submission (back-pressure).  (Taking the first slot whose submission has completed instead
+// -- submissions on different streams complete out of order -- was measured with 16 submitting
+// threads: no gain on 1,024 1080p or 64 8192x8192 files, 2-4 % slower on 8,192 small images and on
+// the host-entropy path, where the queries under the shared lock cost more than the rare wait:
+// profiles/r02b/ab_ring_order.txt.)
+int take_slot(jb_ctx *ctx, Slot **out) {
+  Slot &s = ctx->slots[ctx->next_slot];
+  if (s.busy) {
+    JB_HIP(ctx, hipEventSynchronize(s.done));
+    s.busy = false;
+  }
+  *out = &s;
+  return JB_OK;
+}
+
 int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
   int rc = jb_geometry_of(d, g);
   if (rc == JB_ERR_NULL) return fail(ctx, rc, "null descriptor");
@@ -463,11 +479,10 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
     return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
                 desc->width, desc->height);
   DeviceGuard guard(ctx->device);
-  Slot &s = ctx->slots[ctx->next_slot];
-  if (s.busy) {  // ring full: wait for the oldest submission
-    JB_HIP(ctx, hipEventSynchronize(s.done));
-    s.busy = false;
-  }
+  Slot *slot = nullptr;
+  rc = take_slot(ctx, &slot);
+  if (rc) return rc;
+  Slot &s = *slot;
   // One image: upload + kernel on the primary stream, download on the second (ordered by an
   // event), so the link runs both ways even with a single submitter.  A group of small images
   // runs whole on one stream and consecutive groups alternate between the two streams: with many
@@ -612,11 +627,10 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
                 desc->width, desc->height);
   DeviceGuard guard(ctx->device);
-  Slot &s = ctx->slots[ctx->next_slot];
-  if (s.busy) {
-    JB_HIP(ctx, hipEventSynchronize(s.done));
-    s.busy = false;
-  }
+  Slot *slot = nullptr;
+  rc = take_slot(ctx, &slot);
+  if (rc) return rc;
+  Slot &s = *slot;
   // the whole submission on one stream of the pool, consecutive submissions on different ones
   hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
   if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
