@@ -571,6 +571,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
       if (st.blk >= nb) st.blk = 0;
     }
   }
+  const bool overran = active && bit > end_bit;  // the chunk before consumed bits beyond this one's (= the interval's) end
   if (bit > end_bit) bit = end_bit;
   if (block_end > img.n_blocks) block_end = img.n_blocks;  // (the output is sized for n_blocks)
   Stream s;
@@ -597,7 +598,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   }
   if (active) {
     if (last) {
-      if (block + st.nblk != block_end || st.k != 0) err |= 2;  // the interval's data ends before its blocks do
+      // the interval's data ends before its blocks do, or its last symbol reaches beyond its last byte
+      // (the host decoder's "entropy-coded data ends early": jb_frontend.cpp decode_interval)
+      if (block + st.nblk != block_end || st.k != 0 || (uint32_t)s.bitpos() > end_bit || overran) err |= 2;
     } else if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta) {
       err |= 4;  // this chunk does not end where the synchronisation passes said it would
     }

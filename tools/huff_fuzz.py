@@ -68,7 +68,7 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     base = seeds()
-    counts, agree, t0 = {}, 0, time.time()
+    counts, agree, lenient, t0 = {}, 0, 0, time.time()
     with jb.Context(0) as ctx:
         for s in base:  # the unmutated seeds decode and agree
             _, _, cd = ctx.entropy_decode_device(bytes(s))
@@ -92,9 +92,19 @@ def main():
                 if ch is not None:
                     assert np.array_equal(cd, ch), "device and host decoders disagree on a stream both accept"
                     agree += 1
+                else:
+                    # the host decoder is the authority: the device must not accept what it rejects
+                    lenient += 1
+                    if lenient <= 3:
+                        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", f"huff_fuzz_lenient_{lenient}.jpg")
+                        try:
+                            open(out, "wb").write(data)
+                        except OSError:
+                            pass
     total = sum(counts.values())
     os.environ.pop("JPEGBLK_HUFF_MODE", None)
-    print(f"huff fuzz ok (files with DRI through either device decoder at random): {total} mutants, statuses {dict(sorted(counts.items()))}, {agree} accepted by both decoders and equal")
+    print(f"huff fuzz ok (files with DRI through either device decoder at random): {total} mutants, statuses {dict(sorted(counts.items()))}, {agree} accepted by both decoders and equal, {lenient} accepted by the device decoder alone")
+    assert lenient == 0, "the device decoder accepted streams the host decoder rejects (saved under gpurun_out/)"
 
 
 if __name__ == "__main__":
