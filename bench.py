@@ -32,7 +32,8 @@ Prints ONE JSON line on rank 0:  metric = Mpixels/s decoded (whole job), plus
                through jb_batch_decoder: parse + byte de-stuffing on the host threads, Huffman
                decoding + IDCT + colour on the device, pixels into pinned host memory (PCIe-
                inclusive, so never `value`); images/s = all ranks' images / the slowest rank's wall;
-               at N=1 also with the entropy stage on the host threads (north_star's split);
+               at N=1 also with the entropy stage on the host threads (north_star's split); and
+               with the decoded images left in device memory (jb_batch_decoder_set_device_output);
   cpu_baseline the reference CPU path (oracle/_ref, the genuine reference compiled in place,
                kind "reference") or, if that build is absent, the C restatement (kind "port"),
                timed on this box's host cores on a bounded sample -- rank 0, N=1 only.
@@ -148,7 +149,7 @@ E2E_CONFIGS = [
 ]
 
 
-def end_to_end(jb, np, dist, dev_index, reduce_device, rank, world, tmpdir):
+def end_to_end(jb, np, torch, dist, dev_index, reduce_device, rank, world, tmpdir):
     """decode(path) over batches of files, every rank its own share; -> dict (identical on all ranks)."""
     from jpeg_decoder_amd import synth
     from jpeg_decoder_amd.shard import job_throughput
@@ -204,6 +205,33 @@ def end_to_end(jb, np, dist, dev_index, reduce_device, rank, world, tmpdir):
                                            "wall_s": round(best, 4), "walls": [round(x, 4) for x in walls], "images": int(n_all),
                                            "entropy_stage_ran_on_device": bool(on_device), "pixels_checked_per_rank": 4}
         os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+        # the same batch with the decoded images left in device memory (jb_batch_decoder_set_device_output):
+        # nothing is downloaded, so this is what the pipeline does when the link is not in the way
+        per = (g.rgb_bytes + 255) // 256 * 256
+        region = torch.empty(per_gpu * per, dtype=torch.uint8, device=f"cuda:{dev_index}")
+        with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes) as dec:
+            dec.set_device_output(region.data_ptr(), region.numel())
+            dec.run_to_device(files[:threads])
+            walls = []
+            for k in range(3):
+                if dist is not None:
+                    dist.barrier()
+                ptrs, dims, st, tm = dec.run_to_device(files)
+                if any(x != 0 for x in st):
+                    raise RuntimeError(f"end_to_end {key} (device output): statuses {sorted(set(st))}")
+                if k == 0:
+                    for i in range(4):
+                        off = ptrs[i] - region.data_ptr()
+                        if not np.array_equal(region[off:off + g.rgb_bytes].cpu().numpy().reshape(want[i % 2].shape), want[i % 2]):
+                            raise RuntimeError(f"end_to_end {key} (device output): image {i} differs from the single-image decode")
+                n_all, wall = job_throughput(dist, reduce_device, per_gpu, tm["wall_s"])
+                walls.append(wall)
+        best = min(walls)
+        res["entropy_on_device_pixels_stay_in_hbm"] = {"images_per_s": round(n_all / best, 1), "mpix_s": round(n_all * w * h / best / 1e6, 1),
+                                                       "wall_s": round(best, 4), "walls": [round(x, 4) for x in walls], "images": int(n_all),
+                                                       "pixels_checked_per_rank": 4}
+        del region
+        torch.cuda.empty_cache()
         out["runs"][key] = res
         for p_ in paths:
             os.remove(p_)
@@ -368,7 +396,7 @@ def main():
     if not args.no_e2e:
         import tempfile
         with tempfile.TemporaryDirectory(dir="/tmp") as tmpdir:
-            e2e = end_to_end(jb, np, dist, local_rank, dev if backend == "nccl" else torch.device("cpu"), rank, world, tmpdir)
+            e2e = end_to_end(jb, np, torch, dist, local_rank, dev if backend == "nccl" else torch.device("cpu"), rank, world, tmpdir)
 
     if rank == 0:
         traffic, traffic_note = None, "no profiles/pmc_latest.json"

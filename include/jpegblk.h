@@ -292,6 +292,16 @@ long long jb_batch_decoder_device_entropy_images(const jb_batch_decoder *dec);
  * does not fit fails with JB_ERR_CAPACITY.  Without an arena the pixels go through per-thread
  * pinned staging and are copied into malloc'ed buffers (release with jb_free). */
 int jb_batch_decoder_set_arena(jb_batch_decoder *dec, size_t bytes);
+/* Device-resident output: the decoded images stay in HBM.  `d_base` is DEVICE memory of the
+ * decoder's device that the caller owns (hipMalloc, a torch tensor's storage; 256-byte aligned),
+ * `bytes` its size; jb_batch_decoder_run then places every image in it like in an arena -- rgb[i]
+ * is a DEVICE pointer into the region (tight rows, 3*width bytes each; images decoded in one group
+ * lie back to back, so an image's address has no particular alignment), valid until the next run --
+ * and the fused kernel writes the pixels straight there:
+ * nothing is downloaded, which removes what bounds the host-output forms (the device-to-host link).
+ * For consumers that work on the pixels on the GPU.  The run returns when every image is complete
+ * in device memory.  (NULL, 0) returns to host output; single-device decoders only. */
+int jb_batch_decoder_set_device_output(jb_batch_decoder *dec, void *d_base, size_t bytes);
 /* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,

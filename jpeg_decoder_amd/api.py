@@ -131,6 +131,8 @@ def lib():
     L.jb_poll.argtypes = [vp, ctypes.c_int]
     L.jb_submit_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
     L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
+    L.jb_batch_decoder_set_device_output.argtypes = [vp, vp, ctypes.c_size_t]
+    L.jb_batch_decoder_set_device_output.restype = ctypes.c_int
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
@@ -332,6 +334,7 @@ class BatchDecoder:
         else:
             _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
         self._arena = False
+        self._device_out = False
         if arena_bytes:
             _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))
             self._arena = True
@@ -341,7 +344,30 @@ class BatchDecoder:
         return lib().jb_batch_decoder_device_entropy_images(self._h)
 
     def run(self, paths, keep_pixels=True, on_image=None):
+        assert not self._device_out, "device output is set: use run_to_device"
         return decode_batch(paths, keep_pixels=keep_pixels, on_image=on_image, _decoder=self._h, _arena=self._arena)
+
+    def set_device_output(self, d_base, nbytes):
+        """jb_batch_decoder_set_device_output: decoded images stay in the caller's DEVICE memory
+        [d_base, d_base + nbytes) (e.g. a torch uint8 CUDA tensor's data_ptr()); (0, 0) = host output again."""
+        _check(lib().jb_batch_decoder_set_device_output(self._h, ctypes.c_void_p(d_base or None), nbytes))
+        self._arena = bool(d_base)
+        self._device_out = bool(d_base)
+
+    def run_to_device(self, paths):
+        """After set_device_output: -> (device pointers (int, 0 = failed), (width, height) per image, statuses, times)."""
+        assert getattr(self, "_device_out", False), "call set_device_output first"
+        n = len(paths)
+        arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        rgb = (ctypes.c_void_p * n)()
+        w = (ctypes.c_int32 * n)()
+        h = (ctypes.c_int32 * n)()
+        st = (ctypes.c_int * n)()
+        times = (ctypes.c_double * 4)()
+        rc = lib().jb_batch_decoder_run(self._h, arr, n, rgb, w, h, st, times)
+        t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc,
+             "error": lib().jb_last_error(None).decode(errors="replace") if rc else ""}
+        return [int(rgb[i] or 0) for i in range(n)], [(w[i], h[i]) for i in range(n)], list(st), t
 
     def close(self):
         if self._h:

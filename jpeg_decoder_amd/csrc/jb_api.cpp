@@ -465,8 +465,10 @@ constexpr int kMaxBatch = 256;  // images per submission (the slot's table block
 // One submission of the staging ring: n_images images of one geometry, coefficients contiguous
 // (image stride = coef_bytes), tables per image, pixels contiguous with tight rows -- or, for
 // n_images == 1, any row stride.
+// dst_device: `rgb` is DEVICE memory of ctx's device -- the kernel writes the pixels there and nothing
+// is downloaded (jb_batch_decoder_set_device_output).
 int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef, const uint16_t *qtabs,
-                uint8_t *rgb, int64_t rgb_stride, int *ticket) {
+                uint8_t *rgb, int64_t rgb_stride, int *ticket, bool dst_device = false) {
   if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
   jb_geometry g;
   int rc = check_desc(ctx, desc, &g);
@@ -475,9 +477,10 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   const int64_t dev_stride = 3LL * desc->width;  // tight rows on the device (12-byte stores need no alignment)
   if (rgb_stride < dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
   const size_t coef_total = (size_t)g.coef_bytes * (size_t)n_images, rgb_total = (size_t)g.rgb_bytes * (size_t)n_images;
-  if (coef_total > ctx->max_coef || rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)
+  if (coef_total > ctx->max_coef || (!dst_device && (rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)))
     return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
                 desc->width, desc->height);
+  if (dst_device && rgb_stride != dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "device output has tight rows");
   DeviceGuard guard(ctx->device);
   Slot *slot = nullptr;
   rc = take_slot(ctx, &slot);
@@ -517,21 +520,25 @@ int submit_impl(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int1
   b.coef_image_stride = g.coef_bytes;  // a multiple of 128
   b.d_qtabs = s.d_q;
   b.qtab_image_stride = n_images > 1 ? 768 : 0;
-  b.d_rgb = (uint8_t *)s.d_rgb;
+  b.d_rgb = dst_device ? rgb : (uint8_t *)s.d_rgb;
   b.rgb_row_stride = dev_stride;
   b.rgb_image_stride = g.rgb_bytes;
   rc = jb_blocks_to_rgb_device(ctx, &b, up);
   if (rc) return rc;
-  // the download runs on its own stream, after the kernel: it overlaps the next image's upload
-  if (down != up) {
-    JB_HIP(ctx, hipEventRecord(s.computed, up));
-    JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+  if (dst_device) {
+    down = up;  // the pixels stay on the device: done when the kernel is
+  } else {
+    // the download runs on its own stream, after the kernel: it overlaps the next image's upload
+    if (down != up) {
+      JB_HIP(ctx, hipEventRecord(s.computed, up));
+      JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+    }
+    if (rgb_stride == dev_stride)
+      JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
+    else
+      JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                                   (size_t)desc->height, hipMemcpyDeviceToHost, down));
   }
-  if (rgb_stride == dev_stride)
-    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
-  else
-    JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
-                                 (size_t)desc->height, hipMemcpyDeviceToHost, down));
   JB_HIP(ctx, hipEventRecord(s.done, down));
   s.busy = true;
   s.ticket = ctx->next_ticket++;
@@ -613,7 +620,7 @@ int pack_into_slot(jb_ctx *ctx, Slot &s, const JbHuffJob *const *jobs, int n, in
 // and tables (`desc`, `qtabs` = n x 4*64).
 int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *packed, const JbHuffLayout *lay_in,
                      const jb_image_desc *desc_in, const uint16_t *qtabs_in, int n_images, uint8_t *rgb, int64_t rgb_stride,
-                     uint32_t *status_out, int *ticket) {
+                     uint32_t *status_out, int *ticket, bool dst_device = false) {
   if (ctx->n_slots == 0) return fail(ctx, JB_ERR_CAPACITY, "context was created without staging buffers");
   if (n_images < 1 || n_images > kMaxBatch) return fail(ctx, JB_ERR_GEOMETRY, "n_images = %d outside 1..%d", n_images, kMaxBatch);
   const jb_image_desc *desc = jobs ? &jobs[0]->desc : desc_in;
@@ -623,9 +630,10 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   const int64_t dev_stride = 3LL * desc->width;
   if (rgb_stride < dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "rgb_stride %lld < 3*width", (long long)rgb_stride);
   const size_t coef_total = (size_t)g.coef_bytes * (size_t)n_images, rgb_total = (size_t)g.rgb_bytes * (size_t)n_images;
-  if (coef_total > ctx->max_coef || rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)
+  if (coef_total > ctx->max_coef || (!dst_device && (rgb_total > ctx->rgb_alloc || rgb_total > ctx->max_rgb)))
     return fail(ctx, JB_ERR_CAPACITY, "%d image(s) of %dx%d exceed the capacity the context was created with", n_images,
                 desc->width, desc->height);
+  if (dst_device && rgb_stride != dev_stride) return fail(ctx, JB_ERR_GEOMETRY, "device output has tight rows");
   DeviceGuard guard(ctx->device);
   Slot *slot = nullptr;
   rc = take_slot(ctx, &slot);
@@ -669,20 +677,24 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   b.coef_image_stride = g.coef_bytes;
   b.d_qtabs = s.d_q;
   b.qtab_image_stride = n_images > 1 ? 768 : 0;
-  b.d_rgb = (uint8_t *)s.d_rgb;
+  b.d_rgb = dst_device ? rgb : (uint8_t *)s.d_rgb;
   b.rgb_row_stride = dev_stride;
   b.rgb_image_stride = g.rgb_bytes;
   rc = jb_blocks_to_rgb_device(ctx, &b, up);
   if (rc) return rc;
-  if (down != up) {
-    JB_HIP(ctx, hipEventRecord(s.computed, up));
-    JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+  if (dst_device) {
+    down = up;  // the pixels stay on the device; only the status words come back
+  } else {
+    if (down != up) {
+      JB_HIP(ctx, hipEventRecord(s.computed, up));
+      JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
+    }
+    if (rgb_stride == dev_stride)
+      JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
+    else
+      JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                                   (size_t)desc->height, hipMemcpyDeviceToHost, down));
   }
-  if (rgb_stride == dev_stride)
-    JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
-  else
-    JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
-                                 (size_t)desc->height, hipMemcpyDeviceToHost, down));
   // the status words travel with the pixels: into the caller's (pinned) words when it keeps its own
   // -- many threads share this ring, a slot's words may be recycled before their owner looks -- else
   // into the slot's, which jb_wait / jb_poll check
@@ -776,8 +788,14 @@ int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_
 
 // several prepared images of ONE geometry in one submission (jb_batch.cpp); pixels contiguous, tight rows
 int jb_submit_packed_(jb_ctx *ctx, const jb_image_desc *desc, const uint16_t *qtabs, const uint8_t *packed, const JbHuffLayout *lay,
-                      uint8_t *rgb, uint32_t *status_out, int *ticket) {
-  return submit_jobs_impl(ctx, nullptr, packed, lay, desc, qtabs, lay->n, rgb, 3LL * desc->width, status_out, ticket);
+                      uint8_t *rgb, uint32_t *status_out, int *ticket, int dst_device) {
+  return submit_jobs_impl(ctx, nullptr, packed, lay, desc, qtabs, lay->n, rgb, 3LL * desc->width, status_out, ticket, dst_device != 0);
+}
+
+// jb_submit_batch with the pixels left in DEVICE memory of the context's device (jb_batch.cpp)
+int jb_submit_batch_dev_(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef, const uint16_t *qtabs,
+                         uint8_t *d_rgb, int *ticket) {
+  return submit_impl(ctx, desc, n_images, coef, qtabs, d_rgb, 3LL * desc->width, ticket, true);
 }
 
 int jb_submit(jb_ctx *ctx, const jb_image_desc *desc, const int16_t *coef, const uint16_t *qtabs,

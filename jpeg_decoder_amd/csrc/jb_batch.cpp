@@ -33,8 +33,11 @@ struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
 // device-side entropy decoding: several prepared images of one geometry in one submission; the
 // images' status words (0 = decoded cleanly) are copied to `status_out` (pinned) with the pixels
+// (dst_device: `rgb` is device memory of the context's device, nothing is downloaded)
 extern "C" int jb_submit_packed_(jb_ctx *ctx, const jb_image_desc *desc, const uint16_t *qtabs, const uint8_t *packed,
-                                 const JbHuffLayout *lay, uint8_t *rgb, uint32_t *status_out, int *ticket);
+                                 const JbHuffLayout *lay, uint8_t *rgb, uint32_t *status_out, int *ticket, int dst_device);
+extern "C" int jb_submit_batch_dev_(jb_ctx *ctx, const jb_image_desc *desc, int n_images, const int16_t *coef, const uint16_t *qtabs,
+                                    uint8_t *d_rgb, int *ticket);
 // jb_wait in two halves, so that many threads can wait on one shared context (jb_api.cpp):
 // under the caller's lock, the event to block on (nullptr: the submission has completed) ...
 void *jb_wait_begin_(jb_ctx *ctx, int ticket);
@@ -212,6 +215,8 @@ struct Lane {
 struct Arena {
   uint8_t *base = nullptr;
   size_t bytes = 0;
+  bool on_device = false;  // the caller's DEVICE memory (jb_batch_decoder_set_device_output): the pixels stay in HBM
+  bool owned = true;       // pinned memory this decoder allocated
   std::atomic<size_t> used{0};
   uint8_t *take(size_t n) {
     n = (n + 255) & ~(size_t)255;
@@ -310,6 +315,7 @@ constexpr int kMaxGroup = 64;
 void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, int setup_rc, const std::string &setup_text) {
   jb_bind_thread_near_device_(r.device);
   const bool use_arena = r.arena && r.arena->base;
+  const bool to_device = use_arena && r.arena->on_device;
   double t_entropy = 0, t_wait = 0, t_read = 0;
   // the rest of a file whose head was parsed in pass 1
   auto load = [&](Parsed &p, int i) {
@@ -389,7 +395,8 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
           void *ev2 = nullptr;
           {
             std::lock_guard<std::mutex> lk(r.dev->mu);
-            st_j = jb_submit_batch(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket);
+            st_j = to_device ? jb_submit_batch_dev_(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket)
+                             : jb_submit_batch(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket);
             if (st_j == JB_OK) ev2 = jb_wait_begin_(r.dev->ctx, ticket);
             else text_j = jb_last_error(r.dev->ctx);
           }
@@ -532,7 +539,9 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       // transfers and the kernel run while this thread decodes its next group
       std::lock_guard<std::mutex> lk(r.dev->mu);
       if (on_device) {
-        st = jb_submit_packed_(r.dev->ctx, &head.desc, qtabs.data(), lane->blob[s], &lay, dst, lane->status[s], &grp[s].ticket);
+        st = jb_submit_packed_(r.dev->ctx, &head.desc, qtabs.data(), lane->blob[s], &lay, dst, lane->status[s], &grp[s].ticket, to_device);
+      } else if (to_device) {
+        st = jb_submit_batch_dev_(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
       } else {
         st = jb_submit_batch(r.dev->ctx, &head.desc, n, lane->coef[s], qtabs.data(), dst, &grp[s].ticket);
       }
@@ -757,17 +766,19 @@ extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
   for (jb_batch_decoder *p : d->parts) jb_batch_decoder_destroy(p);
   for (auto &l : d->lanes) l.release();
   jb_ctx_destroy(d->ctx);
-  jb_pinned_free(d->own_arena.base);
+  if (d->own_arena.owned) jb_pinned_free(d->own_arena.base);
   delete d;
 }
 
 extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
   if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_arena: decoder is NULL");
   if (d->arena != &d->own_arena) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: set the arena on the multi-device decoder, not on one of its parts");
-  jb_pinned_free(d->own_arena.base);
+  if (d->own_arena.owned) jb_pinned_free(d->own_arena.base);
   d->own_arena.base = nullptr;
   d->own_arena.bytes = 0;
   d->own_arena.used = 0;
+  d->own_arena.on_device = false;
+  d->own_arena.owned = true;
   if (bytes) {
     // pinned against the (first) device of the decoder; portable, so every device copies into it
     d->own_arena.base = (uint8_t *)jb_pinned_alloc_on(d->device, bytes);
@@ -777,6 +788,24 @@ extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
     for (auto &l : d->lanes) l.drop_out();
     for (jb_batch_decoder *p : d->parts)
       for (auto &l : p->lanes) l.drop_out();
+  }
+  return JB_OK;
+}
+
+extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_base, size_t bytes) {
+  if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: decoder is NULL");
+  if (!d->parts.empty() || d->arena != &d->own_arena)
+    return jb_fail_(nullptr, JB_ERR_UNSUPPORTED, "jb_batch_decoder_set_device_output: single-device decoders only (one output region per device)");
+  if ((d_base == nullptr) != (bytes == 0)) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: pointer and size must both be given or both be zero");
+  if ((uintptr_t)d_base & 255) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_output: the region must be 256-byte aligned");
+  int rc = jb_batch_decoder_set_arena(d, 0);  // releases a pinned arena, forgets an earlier device region
+  if (rc != JB_OK) return rc;
+  if (d_base) {
+    d->own_arena.base = (uint8_t *)d_base;
+    d->own_arena.bytes = bytes;
+    d->own_arena.on_device = true;
+    d->own_arena.owned = false;
+    for (auto &l : d->lanes) l.drop_out();  // no pixel staging: nothing is downloaded
   }
   return JB_OK;
 }

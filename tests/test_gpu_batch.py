@@ -269,3 +269,59 @@ def test_batch_decoder_soak_short():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_soak.py"), "--seconds", "10", "--seed", "3"],
                        capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0 and "batch soak ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+@pytest.mark.parametrize("entropy", ["host", "device"])
+def test_batch_decoder_device_resident_output(jb, oracle, tmp_path, monkeypatch, entropy):
+    """jb_batch_decoder_set_device_output: the decoded images stay in the caller's device memory (a
+    torch tensor here).  The reference's bundled images, writer files with and without restart
+    intervals in groups, one damaged file (flagged by the device decoder, re-decoded through the host
+    path into the same region -- or rejected) and a progressive one: every image copied back from the
+    device equals the host-output decode; then host output again with the same decoder."""
+    import torch
+    from conftest import BASELINE_IMAGES, GOLD
+    if entropy == "host":
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    else:
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    paths = [os.path.join(GOLD, "images", n + ".jpg") for n in BASELINE_IMAGES]
+    more, _ = _write_files(str(tmp_path), "g", 640, 360, 2, 2, 9, 3, 10, oracle)
+    plain, _ = _write_files(str(tmp_path), "p", 333, 211, 1, 1, 5, 2, 0, oracle)
+    data = bytearray(open(more[4], "rb").read())
+    sos = data.index(b"\xff\xda")
+    for k in range(300, 340):
+        if data[sos + k] != 0xff and data[sos + k - 1] != 0xff:
+            data[sos + k] = (data[sos + k] * 7 + 13) % 255
+    open(more[4], "wb").write(bytes(data))
+    prog = os.path.join(GOLD, "images", "prograssive-sample-2.jpg")
+    paths = paths + more + plain + ([prog] if os.path.exists(prog) else [])
+    with jb.BatchDecoder(4, 0) as dec:
+        want, st_want, _ = dec.run(paths)                       # host output: the expectation
+        region = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda:0")
+        dec.set_device_output(region.data_ptr(), region.numel())
+        for _ in range(2):                                       # the region is recycled by every run
+            ptrs, dims, st, tm = dec.run_to_device(paths)
+            torch.cuda.synchronize()
+            assert st == st_want, (st, st_want)
+            for i, p in enumerate(paths):
+                if st[i] != 0:
+                    assert ptrs[i] == 0
+                    continue
+                w, h = dims[i]
+                off = ptrs[i] - region.data_ptr()
+                assert 0 <= off and off + w * h * 3 <= region.numel()
+                got = region[off:off + w * h * 3].cpu().numpy().reshape(h, w, 3)
+                assert np.array_equal(got, want[i]), p
+        with pytest.raises(AssertionError):
+            dec.run(paths)                                       # (the Python wrapper refuses to read device pointers as host memory)
+        # too small a region: the images that do not fit fail with JB_ERR_CAPACITY, the others are right
+        small = torch.zeros(2 << 20, dtype=torch.uint8, device="cuda:0")
+        dec.set_device_output(small.data_ptr(), small.numel())
+        ptrs, dims, st, tm = dec.run_to_device(paths)
+        assert -5 in st and 0 in st
+        dec.set_device_output(0, 0)
+        again, st2, _ = dec.run(paths)
+        assert st2 == st_want and all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(again, want))
+    with jb.BatchDecoder(2, 0, devices=[0, 0]) as multi:
+        with pytest.raises(jb.JbError):
+            multi.set_device_output(region.data_ptr(), region.numel())

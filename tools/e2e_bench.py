@@ -97,6 +97,33 @@ def pinned_array(nbytes, dtype):
     return p, a
 
 
+def device_output_run(jb, paths, want, threads, device, g0, args, w, h, world):
+    """The batch with the decoded images left in device memory: no download at all."""
+    import torch
+    n = len(paths)
+    per = (g0.rgb_bytes + 255) // 256 * 256
+    region = torch.empty(n * per, dtype=torch.uint8, device=f"cuda:{device}")
+    with jb.BatchDecoder(threads, device, g0.coef_bytes, g0.rgb_bytes) as dec:
+        dec.set_device_output(region.data_ptr(), region.numel())
+        dec.run_to_device(paths[:threads])
+        runs = []
+        for k in range(args.repeat):
+            ptrs, dims, st, tm = dec.run_to_device(paths)
+            assert all(x == 0 for x in st), st[:8]
+            if k == 0:   # every image, copied back after the clock has stopped
+                for i, p in enumerate(paths):
+                    off = ptrs[i] - region.data_ptr()
+                    got = region[off:off + g0.rgb_bytes].cpu().numpy().reshape(want[p].shape)
+                    assert np.array_equal(got, want[p]), f"device output: image {i} differs from the single-image decode"
+            runs.append(tm)
+        on_device = dec.device_entropy_images
+    tm = min(runs, key=lambda x: x["wall_s"])
+    return {"output": "device memory (nothing downloaded)", "threads": threads, "images_per_s": round(args.n / tm["wall_s"], 1),
+            "mpix_per_s": round(args.n * w * h / tm["wall_s"] / 1e6, 1), "entropy_cpu_s": round(tm["entropy_s"], 3),
+            "submit_wait_s": round(tm["device_s"], 3), "wall_s": round(tm["wall_s"], 3), "walls": [round(x["wall_s"], 3) for x in runs],
+            "n_gpus": world, "pixels_checked": n, "entropy_on_device": bool(on_device)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
@@ -105,7 +132,7 @@ def main():
     ap.add_argument("--threads", default="1,8,16,32,64")
     ap.add_argument("--source", default="pil", choices=["pil", "writer"])
     ap.add_argument("--distinct", type=int, default=8)
-    ap.add_argument("--modes", default="malloc,arena")
+    ap.add_argument("--modes", default="malloc,arena", help="malloc | arena (pinned host arena) | device (pixels stay in HBM), comma separated")
     ap.add_argument("--dri", type=int, default=0, help="restart interval of the generated files in MCU rows (0 = none); files with "
                     "the batch decoder decodes the entropy stage on the device by default, JPEGBLK_GPU_HUFFMAN=0 on the host threads")
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
@@ -146,6 +173,9 @@ def main():
         # malloc'ed per-image buffers), "arena" = a pinned output arena owned by the decoder
         for mode, t in [(m, int(x)) for m in args.modes.split(",") for x in args.threads.split(",")]:
             arena = (n_mine * ((g0.rgb_bytes + 255) // 256 * 256)) if mode == "arena" else 0
+            if mode == "device":   # device-resident output: the pixels stay in HBM (jb_batch_decoder_set_device_output)
+                res.append(device_output_run(jb, paths, want, t, device, g0, args, w, h, world))
+                continue
             with jb.BatchDecoder(t, device, g0.coef_bytes, g0.rgb_bytes, arena_bytes=arena) as dec:
                 dec.run(paths[:t], keep_pixels=False)          # touch every lane once
                 bad = []
