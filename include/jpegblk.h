@@ -211,11 +211,13 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
                          int n_threads);
 /* The entropy stage ON THE DEVICE (beyond the reference, whose decodeHuffman() -- jpeg.cpp:405-446 --
  * is serial host code): the host only parses the headers and removes the byte stuffing.  Files with
- * restart intervals (DRI; e.g. the reference's images/img4.jpg): every interval is Huffman-decoded
- * by its own GPU lane (the DC predictors reset at each restart, jpeg.cpp:419-425, so intervals are
- * independent).  Files without (the reference's other bundled images, most files anywhere): the
- * self-synchronising decoder -- one lane per 256-byte chunk of the scan, a few passes in which the
- * lanes fall into step with the true symbol sequence, a verified writing pass, a DC pass.  Both
+ * short restart intervals (DRI; e.g. the reference's images/img4.jpg): every interval is
+ * Huffman-decoded by its own GPU lane (the DC predictors reset at each restart, jpeg.cpp:419-425, so
+ * intervals are independent).  Files without DRI (the reference's other bundled images, most files
+ * anywhere) and files with long intervals: the self-synchronising decoder -- one lane per 256-byte
+ * chunk of every interval, a few passes in which the lanes fall into step with the true symbol
+ * sequence, a prefix sum that gives every chunk its block index and DC predictors, and a writing
+ * pass that verifies the chain of chunk states.  Both
  * write straight into the coefficient layout described above.  d_coef is a DEVICE pointer (16-byte aligned,
  * capacity coef_cap_bytes); the result is integer-exact with jb_entropy_decode.  Synchronous.
  * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (restart markers that do not match
