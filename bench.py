@@ -66,10 +66,12 @@ EXTRA_CONFIGS = [
     ("config4_share_1080p_444_x128", "1920x1080-444", 128, 1, "BASELINE config 4, one GPU's share: 128 x 1920x1080 4:4:4 in one launch"),
     ("config5_share_8192_420_x4", "8192x8192-420", 4, 1, "BASELINE config 5 shape: 4 x 8192x8192 4:2:0 in one launch"),
     ("bundled_size_679x451_420_x512", "679x451-420", 512, 1, "the reference's bundled images/img.jpg size, 512 per launch, tightly packed odd-width rows"),
+    ("bundled_size_679x451_420_x512_pitch2048", "679x451-420@2048", 512, 1, "the same 512 images with a row pitch of 2048 bytes (the next multiple of 64 above 3*679 = 2037): what a caller that chooses its pitch gets"),
 ]
 
 
 def parse_workload(text):
+    text = text.split("@")[0]   # ("WxH-SSS@P": row pitch P bytes, Resident reads it)
     dims, samp = text.split("-")
     w, h = (int(v) for v in dims.split("x"))
     hs, vs = SAMPLING[samp]
@@ -245,6 +247,7 @@ class Resident:
         from jpeg_decoder_amd import synth
         from jpeg_decoder_amd.api import torch_batch
         self.w, self.h, self.hs, self.vs = parse_workload(workload)
+        self.pitch = int(workload.split("@")[1]) if "@" in workload else 3 * self.w   # bytes per pixel row in HBM
         self.nimg, self.sets = nimg, sets
         self.desc = jb.make_desc(self.w, self.h, self.hs, self.vs)
         g = self.g = jb.geometry_of(self.desc)
@@ -258,7 +261,7 @@ class Resident:
             coef_t = torch.empty((nimg, g.n_coded_blocks, 64), dtype=torch.int16, device=dev)
             for i in range(nimg):
                 coef_t[i] = torch.roll(base, shifts=((s * nimg + i) * 7919 % max(1, g.mcus_x * g.mcus_y)) * g.blocks_per_mcu, dims=0)
-            rgb_t = torch.zeros((nimg, self.h, 3 * self.w), dtype=torch.uint8, device=dev)
+            rgb_t = torch.zeros((nimg, self.h, self.pitch), dtype=torch.uint8, device=dev)
             self.tensors.append((coef_t, rgb_t))
             self.batches.append(torch_batch(self.desc, nimg, coef_t, self.q_t, rgb_t))
         del base
