@@ -588,6 +588,7 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
   p.state_in = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_in);
   p.chunks = (const JbChunkDesc *)(d + lay.off_chunks);
+  p.cps = (JbCheckpoint *)((uint8_t *)s.d_blob + lay.off_cps);
   p.dcsum = (uint32_t *)((uint8_t *)s.d_blob + lay.off_dcsum);
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
   // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
@@ -1036,7 +1037,8 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   lay->off_state_a = a16(lay->total);
   lay->off_state_b = a16(lay->off_state_a + n_chunks * sizeof(JbChunkState));
   lay->off_state_in = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
-  lay->off_dcsum = a16(lay->off_state_in + n_chunks * sizeof(JbChunkState));
+  lay->off_cps = (a16(lay->off_state_in + n_chunks * sizeof(JbChunkState)) + 31) & ~(size_t)31;
+  lay->off_dcsum = a16(lay->off_cps + n_chunks * 8 * sizeof(JbCheckpoint));
   lay->off_base = a16(lay->off_dcsum + n_chunks * 16);
   lay->device_total = a16(lay->off_base + n_chunks * 16);
   lay->n = n;

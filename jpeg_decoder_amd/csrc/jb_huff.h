@@ -65,6 +65,19 @@ struct JbChunkState {
   uint32_t meta;    // k (0 = a DC symbol is next, else zig-zag position) | block-in-MCU << 8 | blocks completed in the chunk << 16
 };
 
+// A re-decode of a chunk (sync passes r > 0) can stop as soon as it meets the path of the chunk's
+// previous decode: from equal (bit position, k, block-in-MCU) on, everything is the same.  The
+// previous path is remembered at kJbCheckpoints places inside the chunk -- the first symbol boundary
+// at or behind every kJbCheckpointBits bits -- with the counts up to there.
+constexpr uint32_t kJbCheckpointBits = 256;
+constexpr uint32_t kJbCheckpoints = kJbChunkBytes * 8 / kJbCheckpointBits - 1;  // 7 inside a chunk
+struct JbCheckpoint {   // 32 bytes
+  uint32_t bitpos, meta;     // as in JbChunkState, without the block count
+  uint32_t nblk;             // blocks completed in the chunk before this place
+  uint32_t dc[3];            // DC differences summed before this place, per component
+  uint32_t pad[2];
+};
+
 struct JbHuffLaunch {
   const uint8_t *scan;         // device: clean entropy-coded bytes of all images
   const uint32_t *starts;      // device: interval start offsets
@@ -82,6 +95,7 @@ struct JbHuffLaunch {
   JbChunkState *state_a, *state_b;  // device scratch, one entry per chunk each: exit states of the passes, ping-pong
   JbChunkState *state_in;           // device scratch: the start state each chunk was last decoded from
   const JbChunkDesc *chunks;   // device: one descriptor per chunk
+  JbCheckpoint *cps;           // device scratch, 8 records per chunk (kJbCheckpoints used)
   uint32_t *dcsum;             // device scratch, 4 words per chunk: sum of the DC differences decoded in the chunk, per component (Y, Cb, Cr, -)
   uint32_t *base;              // device scratch, 4 words per chunk: index of the block the chunk starts in; DC predictors (Y, Cb, Cr) at its start
   int32_t sync_rounds;         // synchronisation passes (>= 1); n_chunks of them always suffice
@@ -125,7 +139,7 @@ struct JbHuffLayout {
   int64_t coef_stride = 0;
   // the self-synchronising decoder's part: its workgroup list and image list (uploaded), and the
   // device-only scratch behind the uploaded bytes (chunk states x 2, chunk bases)
-  size_t off_sync_wg = 0, off_sync_img = 0, off_chunks = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_dcsum = 0, off_base = 0, device_total = 0;
+  size_t off_sync_wg = 0, off_sync_img = 0, off_chunks = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_cps = 0, off_dcsum = 0, off_base = 0, device_total = 0;
   int n_sync_wg = 0, n_sync_images = 0;
 };
 // Is the device decoder worth taking for this image?  Interval decoder: at least `min_intervals`

@@ -411,12 +411,13 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const uint32_t ci = wg.first_interval + (uint32_t)tid;  // this lane's chunk
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
-  uint32_t bit = 0, end_bit = 0;
+  uint32_t bit = 0, end_bit = 0, nominal_start = 0;
   ChunkLane st{0, 0, 0, 0, 0, 0};
   bool skip = false;  // the start state is the one this chunk was decoded from last time: same results
   if (active) {
     const ChunkExtent x = chunk_extent(p, img, ci);
     end_bit = x.end_bit;
+    nominal_start = x.start_bit;
     JbChunkState in{x.start_bit, 0};
     if (!x.first && round > 0) {
       const JbChunkState prev = src[img.state_off + ci - 1];
@@ -452,6 +453,18 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   s.ring = rings + tid * kRing;
   open_at_bit(s, (active && !skip) ? bit : 0u);
   bool live = active && !skip && bit < end_bit;
+  // checkpoints: the first symbol boundary at or behind every kJbCheckpointBits bits of the chunk.  Pass 0
+  // records the state and the counts there; a later pass that arrives at a checkpoint in the state
+  // recorded for it has met the path of the chunk's previous decode and stops: what follows is known.
+  JbCheckpoint *const cps = p.cps + (size_t)(img.state_off + (active ? ci : 0u)) * 8u;
+  uint32_t cp_i = 0, next_b = nominal_start + kJbCheckpointBits;
+  while (next_b <= bit && cp_i < kJbCheckpoints) {  // a start behind the chunk's first checkpoints (a lane far out of step):
+    if (live) ((uint4 *)(cps + cp_i))[0] = make_uint4(0xffffffffu, 0u, 0u, 0u);  // what they hold is no longer on this chunk's path
+    cp_i++;
+    next_b += kJbCheckpointBits;
+  }
+  bool met = false;
+  uint32_t met_at = 0;
   for (uint32_t step = 0;; step++) {
     if ((step & 3u) == 0) {
       if (__builtin_amdgcn_ballot_w64(live) == 0) break;
@@ -464,12 +477,49 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
         s.consume(1);
         st.k = 0;
       }
-      live = (uint32_t)s.bitpos() < end_bit;
+      const uint32_t bp = (uint32_t)s.bitpos();
+      live = bp < end_bit;
+      if (bp >= next_b && cp_i < kJbCheckpoints) {  // rare: at most kJbCheckpoints times per chunk
+        const uint32_t meta = st.k | (st.blk << 8);
+        uint4 *rec = (uint4 *)(cps + cp_i);
+        if (round > 0 && live) {
+          const uint4 old = rec[0];
+          if (old.x == bp && old.y == meta) {
+            met = true;
+            met_at = cp_i;
+            live = false;
+          }
+        }
+        if (!met) {
+          rec[0] = make_uint4(bp, meta, st.nblk, st.dc0);
+          rec[1] = make_uint4(st.dc1, st.dc2, 0u, 0u);
+        }
+        cp_i++;
+        next_b += kJbCheckpointBits;
+      }
     }
   }
   if (active && !skip) {
-    dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
-    *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(st.dc0, st.dc1, st.dc2, 0u);
+    if (met) {
+      // the rest of the chunk is what the previous decode of this chunk found: its exit state, and its
+      // counts shifted by the difference of the counts at the meeting place; the later checkpoints
+      // (recorded relative to the old counts) move by the same amounts
+      const JbChunkState old_exit = src[img.state_off + ci];
+      const uint4 old_sum = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
+      const uint4 a = ((const uint4 *)(cps + met_at))[0], b = ((const uint4 *)(cps + met_at))[1];
+      const uint32_t d_n = st.nblk - a.z, d0 = st.dc0 - a.w, d1 = st.dc1 - b.x, d2 = st.dc2 - b.y;
+      for (uint32_t i = met_at; i < kJbCheckpoints; i++) {
+        uint4 *rec = (uint4 *)(cps + i);
+        const uint4 r0 = rec[0], r1 = rec[1];
+        rec[0] = make_uint4(r0.x, r0.y, r0.z + d_n, r0.w + d0);
+        rec[1] = make_uint4(r1.x + d1, r1.y + d2, 0u, 0u);
+      }
+      dst[img.state_off + ci] = JbChunkState{old_exit.bitpos, (old_exit.meta & 0xffffu) | ((((old_exit.meta >> 16) + d_n) & 0xffffu) << 16)};
+      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(old_sum.x + d0, old_sum.y + d1, old_sum.z + d2, 0u);
+    } else {
+      dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
+      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(st.dc0, st.dc1, st.dc2, 0u);
+    }
   }
 }
 
@@ -544,7 +594,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   const uint32_t ci = wg.first_interval + (uint32_t)tid;
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
-  uint32_t bit = 0, end_bit = 0, block = 0, block_end = 0;
+  uint32_t bit = 0, end_bit = 0, block = 0, block_end = 0, base0 = 0, base1 = 0, base2 = 0;
   bool last = false;
   ChunkLane st{0, 0, 0, 0, 0, 0};
   JbChunkState want{0, 0};
@@ -556,9 +606,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
     want = fin[img.state_off + ci];
     const uint4 b = ((const uint4 *)p.base)[img.state_off + ci];
     block = b.x;
-    st.dc0 = b.y;
-    st.dc1 = b.z;
-    st.dc2 = b.w;
+    st.dc0 = base0 = b.y;
+    st.dc1 = base1 = b.z;
+    st.dc2 = base2 = b.w;
     // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
     const uint32_t m1 = (x.seg + 1) * img.ri < img.n_mcus ? (x.seg + 1) * img.ri : img.n_mcus;
     block_end = m1 * nb;
@@ -601,8 +651,13 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
       // the interval's data ends before its blocks do, or its last symbol reaches beyond its last byte
       // (the host decoder's "entropy-coded data ends early": jb_frontend.cpp decode_interval)
       if (block + st.nblk != block_end || st.k != 0 || (uint32_t)s.bitpos() > end_bit || overran) err |= 2;
-    } else if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta) {
-      err |= 4;  // this chunk does not end where the synchronisation passes said it would
+    } else {
+      // this chunk must end where the synchronisation passes said it would, after as many blocks, and with
+      // the DC differences adding up to what they recorded (the predictors of the chunks behind it rest on those)
+      const uint4 sums = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
+      if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta ||
+          st.dc0 - base0 != sums.x || st.dc1 - base1 != sums.y || st.dc2 - base2 != sums.z)
+        err |= 4;
     }
     if (err) atomicOr(p.status + wg.image, err);
   }

@@ -65,11 +65,14 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="WxH: just this size (for a kernel trace)")
+    ap.add_argument("--sub", default="", help="444 | 420: just this sampling")
     ap.add_argument("--dri", default="0,1", help="restart interval in MCU rows, comma separated (0 = none)")
     args = ap.parse_args()
     sizes = [(679, 451, "420"), (1920, 1080, "444"), (1920, 1080, "420"), (4096, 4096, "420"), (4096, 4096, "444"), (8192, 8192, "420")]
     if args.only:
         sizes = [x for x in sizes if f"{x[0]}x{x[1]}" == args.only]
+    if args.sub:
+        sizes = [x for x in sizes if x[2] == args.sub]
     rows = []
     with jb.Context(0) as ctx:
         for w, h, sub in sizes:
