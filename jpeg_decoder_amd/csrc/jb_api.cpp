@@ -646,8 +646,13 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   hipStream_t up = ps, down = ps;
   // (all downloads of these submissions on the one download stream instead: 2,175 against 2,640
   // images/s on PIL 1080p files -- not taken; JPEGBLK_DEV_DOWN=1 is that variant, for A/B runs)
-  static const bool one_down = getenv("JPEGBLK_DEV_DOWN") && getenv("JPEGBLK_DEV_DOWN")[0] == '1';
-  if (one_down && ctx->stream2) down = ctx->stream2;
+  static const int n_down = getenv("JPEGBLK_DEV_DOWN") ? atoi(getenv("JPEGBLK_DEV_DOWN")) : 0;  // N dedicated download streams (0: the submission's own)
+  if (n_down == 1 && ctx->stream2) down = ctx->stream2;
+  else if (n_down > 1) {
+    const int k = 1 + (int)((ctx->n_group_submits - 1) % (unsigned)(n_down < jb_ctx::kMaxPairs ? n_down : jb_ctx::kMaxPairs - 1));
+    if (!ctx->pair_down[k]) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pair_down[k], hipStreamNonBlocking));
+    down = ctx->pair_down[k];
+  }
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, jobs ? jobs[i]->qtabs : qtabs_in + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
