@@ -644,8 +644,10 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
   if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   hipStream_t up = ps, down = ps;
-  // (all downloads of these submissions on the one download stream instead: 2,175 against 2,640
-  // images/s on PIL 1080p files -- not taken; JPEGBLK_DEV_DOWN=1 is that variant, for A/B runs)
+  // (downloads of these submissions on 1..4 dedicated download streams instead, JPEGBLK_DEV_DOWN=N: +12-15 %
+  // with one or two on 1,024 1080p files, -20 to -45 % on 8192x8192 files with any number, where a
+  // download that waits for its kernels holds up the ones queued behind it: not taken;
+  // profiles/r02b/ab_dev_download_stream.txt)
   static const int n_down = getenv("JPEGBLK_DEV_DOWN") ? atoi(getenv("JPEGBLK_DEV_DOWN")) : 0;  // N dedicated download streams (0: the submission's own)
   if (n_down == 1 && ctx->stream2) down = ctx->stream2;
   else if (n_down > 1) {
