@@ -125,16 +125,19 @@ struct Parsed {
 
 constexpr int kMaxSlots = 4;
 // pinned buffers per host thread = its submissions in flight: decode group k while k-1 .. k-n+1 are on the device.
-// Two: three or four (JPEGBLK_LANE_SLOTS, A/B knob), smaller groups, and first groups of different sizes per
-// thread (so that the threads' groups do not travel in lock-step) were measured on 1,024 1080p and 64
-// 8192x8192 files and stayed inside the run-to-run spread (profiles/r02b/ab_pipeline_depth.txt)
-int lane_slots() {
-  static const int n = [] {
+// Host output (pageable buffers or the pinned arena) is bound by the download, and there two slots do: three or
+// four, smaller groups, and first groups of different sizes per thread were measured on 1,024 1080p and 64
+// 8192x8192 files and stayed inside the run-to-run spread (profiles/r02b/ab_pipeline_depth.txt).  Device-resident
+// output is bound by the latency of a group's launches: there four slots and smaller groups are worth
+// +35 % (1,024 1080p files: 13,400 -> 18,400 images/s) and +25 % (8192x8192: 1,090 -> 1,420), same file.
+// JPEGBLK_LANE_SLOTS = 2..4 overrides.
+int lane_slots(bool device_output) {
+  static const int forced = [] {
     const char *e = getenv("JPEGBLK_LANE_SLOTS");
-    const int v = e ? atoi(e) : 2;
-    return v < 2 ? 2 : v > kMaxSlots ? kMaxSlots : v;
+    const int v = e ? atoi(e) : 0;
+    return v <= 0 ? 0 : v < 2 ? 2 : v > kMaxSlots ? kMaxSlots : v;
   }();
-  return n;
+  return forced ? forced : device_output ? kMaxSlots : 2;
 }
 
 // what one host thread owns across runs: the pinned buffers its Huffman stage decodes into and,
@@ -158,16 +161,17 @@ struct Lane {
   }
   size_t cap_coef = 0, cap_rgb = 0;
   bool has_out = false;
+  int n_alloc = 0;  // slots with buffers
 
   // `device`: the GPU this lane's decoder drives -- the buffers are pinned against it and come from
   // its NUMA node, whatever device the allocating thread has current (a fresh std::thread: 0)
-  int ensure(int device, size_t need_coef, size_t need_rgb, bool with_out) {
-    if (coef[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out)) return JB_OK;
+  int ensure(int device, size_t need_coef, size_t need_rgb, bool with_out, int n_slots) {
+    if (coef[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out) && n_alloc >= n_slots) return JB_OK;
     if (need_coef < cap_coef) need_coef = cap_coef;
     if (need_rgb < cap_rgb) need_rgb = cap_rgb;
     release();
     int rc = JB_OK;
-    for (int s = 0; s < lane_slots() && rc == JB_OK; s++) {
+    for (int s = 0; s < n_slots && rc == JB_OK; s++) {
       coef[s] = (int16_t *)jb_pinned_alloc_on(device, need_coef);
       if (!coef[s]) rc = JB_ERR_HIP;
       if (rc == JB_OK && !status[s]) {
@@ -183,6 +187,7 @@ struct Lane {
       cap_coef = need_coef;
       cap_rgb = need_rgb;
       has_out = with_out;
+      n_alloc = n_slots;
     } else {
       release();
     }
@@ -207,6 +212,7 @@ struct Lane {
     }
     drop_out();
     cap_coef = cap_rgb = 0;
+    n_alloc = 0;
   }
 };
 
@@ -242,6 +248,7 @@ struct Totals {
 struct Run {
   int device;
   size_t dev_cap_coef, dev_cap_rgb;  // ring-slot capacity: bounds a group whose entropy stage runs on the device
+  int n_slots;                       // submissions a host thread keeps in flight (lane_slots)
   const char *const *paths;
   int n_paths, n_threads, inner_threads;
   const std::vector<std::vector<int>> *lists;  // which files each host thread owns (indices into paths)
@@ -334,7 +341,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
     bool on_device = false;              // the group's entropy stage ran on the device (jb_huff.hip)
   } grp[kMaxSlots];
-  const int kSlots = lane_slots();
+  const int kSlots = r.n_slots;
   // Where the entropy stage runs.  The batch decoder's default is the DEVICE for every baseline image
   // the device decoders take (restart intervals: one lane per interval; none: the self-synchronising
   // decoder), 16 intervals / chunks or more: measured against 16 host threads it is 1.06x (8,192 small
@@ -574,26 +581,30 @@ struct jb_batch_decoder {
   Arena *arena = &own_arena;  // a part of a multi-device decoder points at its parent's arena
   jb_ctx *ctx = nullptr;      // the one context all host threads of this device submit to
   size_t ctx_coef = 0, ctx_rgb = 0;
+  int ctx_ring = 0;
+  int slots() const { return lane_slots(arena->base && arena->on_device); }
   // multi-device decoder (jb_batch_decoder_create_multi): one single-device decoder per listed
   // device; this object then only deals the files out and owns the shared arena
   std::vector<jb_batch_decoder *> parts;
 
   int ensure_ctx(size_t need_coef, size_t need_rgb) {
-    if (ctx && need_coef <= ctx_coef && need_rgb <= ctx_rgb) return JB_OK;
+    // ring depth = everything the host threads can have in flight, so that a submission never blocks a
+    // thread that could be decoding; device memory is not the scarce resource here (32 slots of
+    // 8192x8192 4:2:0 are 13 GB of 288)
+    int ring = slots() * (int)lanes.size();
+    if (ring > 64) ring = 64;
+    if (ctx && need_coef <= ctx_coef && need_rgb <= ctx_rgb && ring <= ctx_ring) return JB_OK;
     if (need_coef < ctx_coef) need_coef = ctx_coef;
     if (need_rgb < ctx_rgb) need_rgb = ctx_rgb;
     jb_ctx_destroy(ctx);
     ctx = nullptr;
     ctx_coef = ctx_rgb = 0;
-    // ring depth = everything the host threads can have in flight (lane_slots() submissions each), so that a
-    // submission never blocks a thread that could be decoding; device memory is not the scarce
-    // resource here (32 slots of 8192x8192 4:2:0 are 13 GB of 288)
-    int ring = lane_slots() * (int)lanes.size();
-    if (ring > 64) ring = 64;
+    ctx_ring = 0;
     int rc = jb_ctx_create(device, need_coef, need_rgb, ring, &ctx);
     if (rc == JB_OK) {
       ctx_coef = need_coef;
       ctx_rgb = need_rgb;
+      ctx_ring = ring;
     }
     return rc;
   }
@@ -607,8 +618,9 @@ struct jb_batch_decoder {
     std::vector<std::thread> th;
     std::vector<int> rcs((size_t)n_lanes, JB_OK);
     const int dev = device;
+    const int n_slots = slots();
     for (int i = 0; i < n_lanes; i++)
-      th.emplace_back([&, i] { rcs[(size_t)i] = lanes[(size_t)i].ensure(dev, need_coef, need_rgb, with_out); });
+      th.emplace_back([&, i, n_slots] { rcs[(size_t)i] = lanes[(size_t)i].ensure(dev, need_coef, need_rgb, with_out, n_slots); });
     for (auto &x : th) x.join();
     for (int r : rcs)
       if (r != JB_OK) return jb_fail_(nullptr, r, "pinned host allocation failed");
@@ -654,7 +666,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // which files each thread owns: file i -> thread i % n_threads
   std::vector<std::vector<int>> lists((size_t)n_threads);
   for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
-  Run r{d->device, 0, 0, paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
+  Run r{d->device, 0, 0, d->slots(), paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
         &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
@@ -696,7 +708,9 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
     if (!(knob && knob[0] == '0')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
-      const long mb = e ? atol(e) : 512;
+      // (device-resident output: nothing is downloaded, a group costs its launches' latency, and many small
+      // groups in flight beat few large ones -- about 100 MB of coefficients each: 8 1080p images, one 8192x8192)
+      const long mb = e ? atol(e) : (d->arena->base && d->arena->on_device) ? 96 : 512;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
       size_t share = (size_t)((n_paths + n_threads - 1) / (n_threads > 0 ? n_threads : 1));
       if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;
@@ -705,8 +719,10 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   }
   int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads, ring_bytes, ring_bytes) : JB_OK;
   if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
-  r.dev_cap_coef = d->ctx_coef;
-  r.dev_cap_rgb = d->ctx_rgb;
+  // a device group is bounded by this run's group size (the ring slots may be larger: an earlier run's)
+  const size_t group_cap = ring_bytes > max_coef ? ring_bytes : max_coef;
+  r.dev_cap_coef = (ring_bytes && group_cap < d->ctx_coef) ? group_cap : d->ctx_coef;
+  r.dev_cap_rgb = (ring_bytes && group_cap < d->ctx_rgb) ? group_cap : d->ctx_rgb;
   // pass 2: entropy decoding on the host threads, all submitting to the shared context
   dev.ctx = d->ctx;
   {

@@ -31,6 +31,7 @@
 // answer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "jb_huff.h"
 #include "jb_kernels.h"
@@ -668,16 +669,19 @@ hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
   if (p.n_wgs > 0) hipLaunchKernelGGL(jb_huff_kernel, dim3((unsigned)p.n_wgs), dim3(kJbHuffLanes), 0, stream, p);
   if (p.n_sync_wgs > 0 && p.n_sync_images > 0) {
     const dim3 grid((unsigned)p.n_sync_wgs), block(kJbHuffLanes);
+    // JPEGBLK_HUFF_EXTRA_LDS=N (experiment): N bytes of unused dynamic LDS per workgroup of the decoding
+    // kernels -- fewer workgroups per CU; how much the chunk decoder depends on occupancy
+    static const unsigned extra_lds = getenv("JPEGBLK_HUFF_EXTRA_LDS") ? (unsigned)atoi(getenv("JPEGBLK_HUFF_EXTRA_LDS")) : 0u;
     const JbChunkState *fin = nullptr;
     const int rounds = p.sync_rounds > 0 ? p.sync_rounds : kJbSyncRounds;
     for (int r = 0; r < rounds; r++) {
       const JbChunkState *src = (r & 1) ? p.state_a : p.state_b;
       JbChunkState *dst = (r & 1) ? p.state_b : p.state_a;
-      hipLaunchKernelGGL(jb_huff_sync_kernel, grid, block, 0, stream, p, r, src, dst);
+      hipLaunchKernelGGL(jb_huff_sync_kernel, grid, block, extra_lds, stream, p, r, src, dst);
       fin = dst;
     }
     hipLaunchKernelGGL(jb_huff_scan_kernel, dim3((unsigned)p.n_sync_images), block, 0, stream, p, fin);
-    hipLaunchKernelGGL(jb_huff_write_kernel, grid, block, 0, stream, p, fin);
+    hipLaunchKernelGGL(jb_huff_write_kernel, grid, block, extra_lds, stream, p, fin);
   }
   return hipGetLastError();
 }
