@@ -162,18 +162,25 @@ struct Lane {
   size_t cap_coef = 0, cap_rgb = 0;
   bool has_out = false;
   int n_alloc = 0;  // slots with buffers
+  int device_of_bufs = 0;
 
   // `device`: the GPU this lane's decoder drives -- the buffers are pinned against it and come from
   // its NUMA node, whatever device the allocating thread has current (a fresh std::thread: 0)
+  // The coefficient staging of a slot is only pinned when the HOST entropy decoder first needs it (host
+  // mode, or an image the device decoder handed back): with the entropy stage on the device it is never
+  // touched -- 16 threads x 4 slots x 100 MB for 8192x8192 files, most of a second of page pinning.
+  int16_t *coef_at(int s) {
+    if (!coef[s]) coef[s] = (int16_t *)jb_pinned_alloc_on(device_of_bufs, cap_coef);
+    return coef[s];
+  }
   int ensure(int device, size_t need_coef, size_t need_rgb, bool with_out, int n_slots) {
-    if (coef[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out) && n_alloc >= n_slots) return JB_OK;
+    if (status[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out) && n_alloc >= n_slots) return JB_OK;
     if (need_coef < cap_coef) need_coef = cap_coef;
     if (need_rgb < cap_rgb) need_rgb = cap_rgb;
     release();
     int rc = JB_OK;
+    device_of_bufs = device;
     for (int s = 0; s < n_slots && rc == JB_OK; s++) {
-      coef[s] = (int16_t *)jb_pinned_alloc_on(device, need_coef);
-      if (!coef[s]) rc = JB_ERR_HIP;
       if (rc == JB_OK && !status[s]) {
         status[s] = (uint32_t *)jb_pinned_alloc_on(device, 4 * 256);
         if (!status[s]) rc = JB_ERR_HIP;
@@ -396,14 +403,15 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       if (st == JB_OK && g.on_device && lane->status[s][j] != 0) {
         // the device decoder met data it calls corrupt: the host decoder is the authority -- this one
         // image again, entropy stage on the host (the slot's coefficient buffer is free: the group is done)
-        st_j = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, lane->coef[s], lane->cap_coef);
+        int16_t *const cbuf = lane->coef_at(s);
+        st_j = cbuf ? jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, cbuf, lane->cap_coef) : (int)JB_ERR_HIP;
         if (st_j == JB_OK) {
           int ticket = -1;
           void *ev2 = nullptr;
           {
             std::lock_guard<std::mutex> lk(r.dev->mu);
-            st_j = to_device ? jb_submit_batch_dev_(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket)
-                             : jb_submit_batch(r.dev->ctx, &p.desc, 1, lane->coef[s], p.qtabs, staged, &ticket);
+            st_j = to_device ? jb_submit_batch_dev_(r.dev->ctx, &p.desc, 1, cbuf, p.qtabs, staged, &ticket)
+                             : jb_submit_batch(r.dev->ctx, &p.desc, 1, cbuf, p.qtabs, staged, &ticket);
             if (st_j == JB_OK) ev2 = jb_wait_begin_(r.dev->ctx, ticket);
             else text_j = jb_last_error(r.dev->ctx);
           }
@@ -485,8 +493,10 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
         continue;
       }
       // fewer files than host threads: the spare threads split each image's restart intervals
-      int st = jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs,
-                                    lane->coef[s] + (size_t)n * (coef_bytes / 2), coef_bytes, r.inner_threads);
+      int16_t *const cbuf = lane->coef_at(s);
+      int st = cbuf ? jb_entropy_decode_mt(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs,
+                                           cbuf + (size_t)n * (coef_bytes / 2), coef_bytes, r.inner_threads)
+                    : (int)JB_ERR_HIP;
       t_entropy += now_s() - a;
       p.bytes.clear();
       p.bytes.shrink_to_fit();
