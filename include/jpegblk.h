@@ -302,8 +302,13 @@ int jb_batch_decoder_set_arena(jb_batch_decoder *dec, size_t bytes);
  * and the fused kernel writes the pixels straight there:
  * nothing is downloaded, which removes what bounds the host-output forms (the device-to-host link).
  * For consumers that work on the pixels on the GPU.  The run returns when every image is complete
- * in device memory.  (NULL, 0) returns to host output; single-device decoders only. */
+ * in device memory.  (NULL, 0) returns to host output.  A multi-device decoder takes one region per
+ * device: jb_batch_decoder_set_device_outputs. */
 int jb_batch_decoder_set_device_output(jb_batch_decoder *dec, void *d_base, size_t bytes);
+/* The same for a multi-device decoder: one region per listed device, in the order given to
+ * jb_batch_decoder_create_multi (d_bases[k] is memory of device_ids[k]); file i lands in the region of
+ * device_ids[i % n_devices].  n = 0: host output again. */
+int jb_batch_decoder_set_device_outputs(jb_batch_decoder *dec, void *const *d_bases, const size_t *bytes, int n);
 /* Output sink replacing the reference's X11 window / unused BMP writer (display.hpp,
  * jpeg.cpp:462-509): binary PPM (P6). */
 int jb_write_ppm(const char *path, const uint8_t *rgb, int32_t width, int32_t height,

@@ -133,6 +133,8 @@ def lib():
     L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
     L.jb_batch_decoder_set_device_output.argtypes = [vp, vp, ctypes.c_size_t]
     L.jb_batch_decoder_set_device_output.restype = ctypes.c_int
+    L.jb_batch_decoder_set_device_outputs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]
+    L.jb_batch_decoder_set_device_outputs.restype = ctypes.c_int
     L.jb_free.argtypes = [vp]
     L.jb_free.restype = None
     L.jb_write_ppm.argtypes = [ctypes.c_char_p, vp, i32, i32, i64]
@@ -353,6 +355,15 @@ class BatchDecoder:
         _check(lib().jb_batch_decoder_set_device_output(self._h, ctypes.c_void_p(d_base or None), nbytes))
         self._arena = bool(d_base)
         self._device_out = bool(d_base)
+
+    def set_device_outputs(self, regions):
+        """jb_batch_decoder_set_device_outputs: [(device pointer, bytes), ...], one per listed device of a
+        multi-device decoder; [] = host output again."""
+        n = len(regions)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[r[0] for r in regions])
+        sizes = (ctypes.c_size_t * max(n, 1))(*[r[1] for r in regions])
+        _check(lib().jb_batch_decoder_set_device_outputs(self._h, ptrs, sizes, n))
+        self._arena = self._device_out = n > 0
 
     def run_to_device(self, paths):
         """After set_device_output: -> (device pointers (int, 0 = failed), (width, height) per image, statuses, times)."""

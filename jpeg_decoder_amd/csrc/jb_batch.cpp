@@ -805,6 +805,15 @@ extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
   d->own_arena.used = 0;
   d->own_arena.on_device = false;
   d->own_arena.owned = true;
+  for (jb_batch_decoder *part : d->parts)  // (device regions of a multi-device decoder are forgotten as well)
+    if (part->arena == &part->own_arena) {
+      part->own_arena.base = nullptr;
+      part->own_arena.bytes = 0;
+      part->own_arena.used = 0;
+      part->own_arena.on_device = false;
+      part->own_arena.owned = true;
+      part->arena = &d->own_arena;
+    }
   if (bytes) {
     // pinned against the (first) device of the decoder; portable, so every device copies into it
     d->own_arena.base = (uint8_t *)jb_pinned_alloc_on(d->device, bytes);
@@ -821,7 +830,7 @@ extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
 extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_base, size_t bytes) {
   if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: decoder is NULL");
   if (!d->parts.empty() || d->arena != &d->own_arena)
-    return jb_fail_(nullptr, JB_ERR_UNSUPPORTED, "jb_batch_decoder_set_device_output: single-device decoders only (one output region per device)");
+    return jb_fail_(nullptr, JB_ERR_UNSUPPORTED, "jb_batch_decoder_set_device_output: a multi-device decoder takes one region per device (jb_batch_decoder_set_device_outputs)");
   if ((d_base == nullptr) != (bytes == 0)) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: pointer and size must both be given or both be zero");
   if ((uintptr_t)d_base & 255) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_output: the region must be 256-byte aligned");
   int rc = jb_batch_decoder_set_arena(d, 0);  // releases a pinned arena, forgets an earlier device region
@@ -832,6 +841,36 @@ extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_b
     d->own_arena.on_device = true;
     d->own_arena.owned = false;
     for (auto &l : d->lanes) l.drop_out();  // no pixel staging: nothing is downloaded
+  }
+  return JB_OK;
+}
+
+// the multi-device form: one region per listed device, in the order of jb_batch_decoder_create_multi
+extern "C" int jb_batch_decoder_set_device_outputs(jb_batch_decoder *d, void *const *d_bases, const size_t *bytes, int n) {
+  if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_outputs: decoder is NULL");
+  if (d->parts.empty()) {
+    if (n != 1 || !d_bases || !bytes) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: a single-device decoder takes one region");
+    return jb_batch_decoder_set_device_output(d, d_bases[0], bytes[0]);
+  }
+  const bool off = n == 0;
+  if (!off && (n != (int)d->parts.size() || !d_bases || !bytes))
+    return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: one region per listed device (or n = 0: host output again)");
+  if (!off)
+    for (int k = 0; k < n; k++)
+      if (!d_bases[k] || !bytes[k] || ((uintptr_t)d_bases[k] & 255))
+        return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: every region needs a 256-byte aligned pointer and a size");
+  int rc = jb_batch_decoder_set_arena(d, 0);  // a shared pinned arena and device regions exclude each other
+  if (rc != JB_OK) return rc;
+  for (size_t k = 0; k < d->parts.size(); k++) {
+    jb_batch_decoder *part = d->parts[k];
+    part->own_arena.base = off ? nullptr : (uint8_t *)d_bases[k];
+    part->own_arena.bytes = off ? 0 : bytes[k];
+    part->own_arena.used = 0;
+    part->own_arena.on_device = !off;
+    part->own_arena.owned = off;
+    part->arena = off ? &d->own_arena : &part->own_arena;  // (host output: the parts share the top decoder's arena, if any)
+    if (!off)
+      for (auto &l : part->lanes) l.drop_out();
   }
   return JB_OK;
 }
@@ -847,6 +886,8 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
   // every part runs its share on its own host threads, concurrently with the others
   const int np = (int)d->parts.size();
   d->own_arena.used = 0;
+  for (jb_batch_decoder *part : d->parts)
+    if (part->arena == &part->own_arena) part->own_arena.used = 0;  // device regions: recycled by every run
   const double t0 = now_s();
   struct Share {
     std::vector<const char *> paths;

@@ -322,6 +322,26 @@ def test_batch_decoder_device_resident_output(jb, oracle, tmp_path, monkeypatch,
         dec.set_device_output(0, 0)
         again, st2, _ = dec.run(paths)
         assert st2 == st_want and all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(again, want))
-    with jb.BatchDecoder(2, 0, devices=[0, 0]) as multi:
+    # a multi-device decoder (the one GPU listed twice): one region per listed device, file i in region i % 2
+    with jb.BatchDecoder(4, 0, devices=[0, 0]) as multi:
         with pytest.raises(jb.JbError):
-            multi.set_device_output(region.data_ptr(), region.numel())
+            multi.set_device_output(region.data_ptr(), region.numel())      # (that is the single-device form)
+        with pytest.raises(jb.JbError):
+            multi.set_device_outputs([(region.data_ptr(), region.numel())])  # one region for two devices
+        second = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda:0")
+        multi.set_device_outputs([(region.data_ptr(), region.numel()), (second.data_ptr(), second.numel())])
+        for _ in range(2):
+            ptrs, dims, st, tm = multi.run_to_device(paths)
+            torch.cuda.synchronize()
+            assert st == st_want
+            for i, p in enumerate(paths):
+                if st[i] != 0:
+                    continue
+                w, h = dims[i]
+                reg = (region, second)[i % 2]
+                off = ptrs[i] - reg.data_ptr()
+                assert 0 <= off and off + w * h * 3 <= reg.numel(), (i, off)
+                assert np.array_equal(reg[off:off + w * h * 3].cpu().numpy().reshape(h, w, 3), want[i]), p
+        multi.set_device_outputs([])
+        again, st2, _ = multi.run(paths)
+        assert st2 == st_want and all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(again, want))
