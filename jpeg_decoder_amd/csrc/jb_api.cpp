@@ -566,10 +566,19 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
     JB_HIP(ctx, hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault));
     JB_HIP(ctx, hipMalloc((void **)&s.d_status, 4 * 256));
   }
-  JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, lay.total, hipMemcpyHostToDevice, up));
-  JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)lay.n, up));
-  // the decoder stores non-zero coefficients only
-  JB_HIP(ctx, hipMemsetAsync(d_out, 0, zero_bytes, up));
+  // (JPEGBLK_HUFF_FETCH=0: always the copy engine; A/B knob)
+  static const bool fetch_by_kernel = !(getenv("JPEGBLK_HUFF_FETCH") && getenv("JPEGBLK_HUFF_FETCH")[0] == '0');
+  if (fetch_by_kernel && lay.total <= ((size_t)4 << 20)) JB_HIP(ctx, jbk_huff_fetch(s.d_blob, h, lay.total, up));
+  else JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, lay.total, hipMemcpyHostToDevice, up));
+  // the decoder stores non-zero coefficients only.  (JPEGBLK_HUFF_ZERO=0: hipMemsetAsync; A/B knob)
+  static const bool zero_by_kernel = !(getenv("JPEGBLK_HUFF_ZERO") && getenv("JPEGBLK_HUFF_ZERO")[0] == '0');
+  if (zero_by_kernel) {
+    JB_HIP(ctx, jbk_huff_zero(s.d_status, 4 * (size_t)lay.n, up));
+    JB_HIP(ctx, jbk_huff_zero(d_out, zero_bytes, up));
+  } else {
+    JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)lay.n, up));
+    JB_HIP(ctx, hipMemsetAsync(d_out, 0, zero_bytes, up));
+  }
   JbHuffLaunch p;
   const uint8_t *d = (const uint8_t *)s.d_blob;
   p.scan = d + lay.off_scan;

@@ -330,14 +330,17 @@ namespace {
 
 struct ChunkLane {
   uint32_t k, blk, nblk;  // position in the block (0 = DC next), block within the MCU, blocks completed
-  uint32_t dc0, dc1, dc2; // sync passes: sum of the DC differences so far; write pass: the DC predictors
 };
+// (the three DC values of a lane -- sync passes: sums of the DC differences so far; write pass: the DC
+// predictors -- are separate variables on purpose: as neighbouring fields of the struct the compiler
+// reads them as an array indexed by the component, and puts the struct into scratch memory -- whose
+// set-up costs the first such kernel of a burst 130 us -- or, promoted, into 6 KiB more LDS)
 
 // one symbol; kStore == false: only the state moves (and the DC differences are summed).  Returns
 // false when the data cannot be what the state says (the caller decides what that means).
 template <bool kStore>
 __device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, const uint8_t *zz, uint32_t slots, uint32_t ny, uint32_t nb,
-                                           ChunkLane &st, int16_t *block_out) {
+                                           ChunkLane &st, uint32_t &dc0, uint32_t &dc1, uint32_t &dc2, int16_t *block_out) {
   const int c = st.blk < ny ? 0 : (int)(st.blk - ny) + 1;
   const bool isdc = st.k == 0;
   const uint32_t slot = (slots >> (isdc ? c : 4 + c)) & 1u;
@@ -353,11 +356,11 @@ __device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, con
   if ((kStore || isdc) && sz) val = extend((bits << len) >> (32 - sz), (int)sz);
   if (isdc) {
     // (unsigned: the sums of a lane that is out of step are garbage and may wrap)
-    const uint32_t pr = (c == 0 ? st.dc0 : c == 1 ? st.dc1 : st.dc2) + (uint32_t)val;
+    const uint32_t pr = (c == 0 ? dc0 : c == 1 ? dc1 : dc2) + (uint32_t)val;
     if (kStore && ((int32_t)pr < -32768 || (int32_t)pr > 32767)) return false;  // a predictor the reference's short cannot hold
-    if (c == 0) st.dc0 = pr;
-    else if (c == 1) st.dc1 = pr;
-    else st.dc2 = pr;
+    dc0 = c == 0 ? pr : dc0;
+    dc1 = c == 1 ? pr : dc1;
+    dc2 = c == 2 ? pr : dc2;
     val = (int32_t)pr;
   }
   if (kStore && (isdc ? val != 0 : sz != 0)) JBH_STORE(block_out[zz[kk & 63]], (int16_t)val);
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const bool active = ci < img.n_chunks;
   const uint32_t nb = img.ny + 2;
   uint32_t bit = 0, end_bit = 0, nominal_start = 0;
-  ChunkLane st{0, 0, 0, 0, 0, 0};
+  ChunkLane st{0, 0, 0};
+  uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
   bool skip = false;  // the start state is the one this chunk was decoded from last time: same results
   if (active) {
     const ChunkExtent x = chunk_extent(p, img, ci);
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       if (live) s.top_up();
     }
     if (live) {
-      if (!chunk_step<false>(s, lds.t, zz, slots, img.ny, nb, st, nullptr)) {
+      if (!chunk_step<false>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, nullptr)) {
         // not a possible continuation of this state: the lane is out of step (or the data is corrupt,
         // which the write pass will report) -- move on by one bit and expect a block to start
         s.consume(1);
@@ -492,8 +496,8 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
           }
         }
         if (!met) {
-          rec[0] = make_uint4(bp, meta, st.nblk, st.dc0);
-          rec[1] = make_uint4(st.dc1, st.dc2, 0u, 0u);
+          rec[0] = make_uint4(bp, meta, st.nblk, dc0);
+          rec[1] = make_uint4(dc1, dc2, 0u, 0u);
         }
         cp_i++;
         next_b += kJbCheckpointBits;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       const JbChunkState old_exit = src[img.state_off + ci];
       const uint4 old_sum = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
       const uint4 a = ((const uint4 *)(cps + met_at))[0], b = ((const uint4 *)(cps + met_at))[1];
-      const uint32_t d_n = st.nblk - a.z, d0 = st.dc0 - a.w, d1 = st.dc1 - b.x, d2 = st.dc2 - b.y;
+      const uint32_t d_n = st.nblk - a.z, d0 = dc0 - a.w, d1 = dc1 - b.x, d2 = dc2 - b.y;
       for (uint32_t i = met_at; i < kJbCheckpoints; i++) {
         uint4 *rec = (uint4 *)(cps + i);
         const uint4 r0 = rec[0], r1 = rec[1];
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(old_sum.x + d0, old_sum.y + d1, old_sum.z + d2, 0u);
     } else {
       dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
-      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(st.dc0, st.dc1, st.dc2, 0u);
+      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(dc0, dc1, dc2, 0u);
     }
   }
 }
@@ -597,7 +601,8 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   const uint32_t nb = img.ny + 2;
   uint32_t bit = 0, end_bit = 0, block = 0, block_end = 0, base0 = 0, base1 = 0, base2 = 0;
   bool last = false;
-  ChunkLane st{0, 0, 0, 0, 0, 0};
+  ChunkLane st{0, 0, 0};
+  uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
   JbChunkState want{0, 0};
   if (active) {
     const ChunkExtent x = chunk_extent(p, img, ci);
@@ -607,9 +612,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
     want = fin[img.state_off + ci];
     const uint4 b = ((const uint4 *)p.base)[img.state_off + ci];
     block = b.x;
-    st.dc0 = base0 = b.y;
-    st.dc1 = base1 = b.z;
-    st.dc2 = base2 = b.w;
+    dc0 = base0 = b.y;
+    dc1 = base1 = b.z;
+    dc2 = base2 = b.w;
     // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
     const uint32_t m1 = (x.seg + 1) * img.ri < img.n_mcus ? (x.seg + 1) * img.ri : img.n_mcus;
     block_end = m1 * nb;
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
       if (live) s.top_up();
     }
     if (live) {
-      if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, coef + (int64_t)(block + st.nblk) * 64)) {
+      if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, coef + (int64_t)(block + st.nblk) * 64)) {
         err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
         live = false;
       } else {
@@ -657,11 +662,40 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
       // the DC differences adding up to what they recorded (the predictors of the chunks behind it rest on those)
       const uint4 sums = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
       if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta ||
-          st.dc0 - base0 != sums.x || st.dc1 - base1 != sums.y || st.dc2 - base2 != sums.z)
+          dc0 - base0 != sums.x || dc1 - base1 != sums.y || dc2 - base2 != sums.z)
         err |= 4;
     }
     if (err) atomicOr(p.status + wg.image, err);
   }
+}
+
+// A small packed submission (one image) is fetched from the pinned host blob by a kernel instead of a
+// copy-engine transfer: the decoding kernels behind it on the stream then start without the ~100 us
+// a compute queue waits for the copy engine's completion (one 1080p decode(bytes): 1.2 ms in all).
+__global__ __launch_bounds__(256) void jb_huff_fetch_kernel(uint4 *dst, const uint4 *src, uint32_t n16) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+// the coefficient area and the status words are zeroed by a kernel of this library as well (the decoders store
+// non-zero coefficients only)
+__global__ __launch_bounds__(256) void jb_huff_zero_kernel(uint4 *dst, uint64_t n16) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256u) dst[i] = z;
+}
+hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  const uint64_t n16 = (bytes + 15) / 16;
+  uint64_t blocks = (n16 + 255u) / 256u;
+  if (blocks > 8192u) blocks = 8192u;
+  hipLaunchKernelGGL(jb_huff_zero_kernel, dim3((unsigned)(blocks ? blocks : 1u)), dim3(256), 0, stream, (uint4 *)d_dst, n16);
+  return hipGetLastError();
+}
+hipError_t jbk_huff_fetch(void *d_dst, const void *h_pinned_src, size_t bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+  unsigned blocks = (n16 + 255u) / 256u;
+  if (blocks > 1024u) blocks = 1024u;
+  hipLaunchKernelGGL(jb_huff_fetch_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, (uint4 *)d_dst, (const uint4 *)h_pinned_src, n16);
+  return hipGetLastError();
 }
 
 hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {

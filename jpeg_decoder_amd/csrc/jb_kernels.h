@@ -35,3 +35,8 @@ const char *jbk_kernel_name(int hs, int vs);
 // Device-side entropy decoder (jb_huff.hip); structures in jb_huff.h.
 struct JbHuffLaunch;
 hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream);
+// small pinned host blob -> device by a kernel (no copy-engine hand-over in front of the decoding kernels);
+// bytes is rounded up to 16: both buffers are allocated with that slack
+// zero `bytes` (rounded up to 16) of device memory by a kernel
+hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream);
+hipError_t jbk_huff_fetch(void *d_dst, const void *h_pinned_src, size_t bytes, hipStream_t stream);
