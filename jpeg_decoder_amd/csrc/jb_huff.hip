@@ -237,13 +237,15 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunc
   bool live = active && count > 0;
   uint32_t blk = 0, mcus_left = count;
   int k = 0;
-  for (uint32_t step = 0;; step++) {
-    if ((step & 3u) == 0) {
-      if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // wave-uniform: every lane of this wave is through
+  // (four steps per top-up as an unrolled inner loop: a step counter tested inside the loop body made the
+  // compiler copy the loop-carried registers back and forth in every iteration -- 16 % of a pass)
+  for (;;) {
+    if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // wave-uniform: every lane of this wave is through
 #ifndef JBH_NO_TOPUP
-      if (live) s.top_up();
+    if (live) s.top_up();
 #endif
-    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
     if (live) {
       const int c = blk < img.ny ? 0 : (int)(blk - img.ny) + 1;
       const bool isdc = k == 0;
@@ -470,11 +472,11 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   }
   bool met = false;
   uint32_t met_at = 0;
-  for (uint32_t step = 0;; step++) {
-    if ((step & 3u) == 0) {
-      if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-      if (live) s.top_up();
-    }
+  for (;;) {
+    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+    if (live) s.top_up();
+#pragma unroll
+    for (int u = 0; u < 4; u++)
     if (live) {
       if (!chunk_step<false>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, nullptr)) {
         // not a possible continuation of this state: the lane is out of step (or the data is corrupt,
@@ -638,17 +640,20 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
   uint32_t err = 0;
   bool live = active && bit < end_bit && block < block_end;
-  for (uint32_t step = 0;; step++) {
-    if ((step & 3u) == 0) {
-      if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-      if (live) s.top_up();
-    }
-    if (live) {
-      if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, coef + (int64_t)(block + st.nblk) * 64)) {
-        err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
-        live = false;
-      } else {
-        live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < block_end;
+  // (four steps per top-up, written as an unrolled inner loop: with the step counter tested in the
+  // loop body the compiler copied a dozen loop-carried registers back and forth in every iteration)
+  for (;;) {
+    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+    if (live) s.top_up();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (live) {
+        if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, coef + (int64_t)(block + st.nblk) * 64)) {
+          err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
+          live = false;
+        } else {
+          live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < block_end;
+        }
       }
     }
   }
