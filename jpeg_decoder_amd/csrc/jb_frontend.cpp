@@ -395,7 +395,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   // (a dozen and a half launches: about 1.3 ms whatever the size, then ~0.4 ms per megabyte of scan)
   // against 5.5 ms per megabyte on one host core, so by default the device takes files of
   // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.2-1.7 ms against 0.7 on the
-  // host, 1920x1080 4:4:4 (760 KB) 1.2 against 4.0, 8192x8192 4:2:0 (17 MB) 9 against 94
+  // host, 1920x1080 4:4:4 (760 KB) 1.0 against 4.0, 8192x8192 4:2:0 (17 MB) 8.5 against 93
   // (tools/single_latency.py).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
   // =1: the device for every file with 16 restart intervals / chunks or more; =2: also fewer intervals.
   // Whatever the device decoder does not take or flags as corrupt goes through the host decoder
