@@ -302,7 +302,9 @@ int jb_batch_decoder_set_arena(jb_batch_decoder *dec, size_t bytes);
  * and the fused kernel writes the pixels straight there:
  * nothing is downloaded, which removes what bounds the host-output forms (the device-to-host link).
  * For consumers that work on the pixels on the GPU.  The run returns when every image is complete
- * in device memory.  (NULL, 0) returns to host output.  A multi-device decoder takes one region per
+ * in device memory.  A region that is not device memory of the decoder's device (a host pointer,
+ * another GPU's memory, a size that reaches beyond the allocation) is refused with JB_ERR_GEOMETRY.
+ * (NULL, 0) returns to host output.  A multi-device decoder takes one region per
  * device: jb_batch_decoder_set_device_outputs. */
 int jb_batch_decoder_set_device_output(jb_batch_decoder *dec, void *d_base, size_t bytes);
 /* The same for a multi-device decoder: one region per listed device, in the order given to

@@ -944,6 +944,30 @@ int jb_wait_block_(jb_ctx *ctx, void *event) {
 // is empty, or JPEGBLK_NUMA=0).  The entropy threads of one rank then read their files, decode and
 // write their pinned staging on the socket their GPU hangs off.  Returns the CPUs in the new mask,
 // 0 = left as it was.
+// Is [p, p + bytes) device memory of `device`?  (jb_batch_decoder_set_device_output: a host pointer or
+// another GPU's memory would fault in the pixel kernel instead of failing here.)
+int jb_check_device_region_(int device, const void *p, size_t bytes) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  DeviceGuard guard(device);
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, JB_ERR_GEOMETRY, "not a pointer the HIP runtime knows (%s): device output needs device memory", hipGetErrorString(e));
+  }
+  if (a.type != hipMemoryTypeDevice) return fail(nullptr, JB_ERR_GEOMETRY, "device output needs device memory (hipMalloc), not host or managed memory");
+  if (a.device != device) return fail(nullptr, JB_ERR_GEOMETRY, "the region is memory of device %d, the decoder drives device %d", a.device, device);
+  // the last byte must belong to the same allocation
+  hipPointerAttribute_t b;
+  memset(&b, 0, sizeof b);
+  e = hipPointerGetAttributes(&b, (const uint8_t *)p + (bytes ? bytes - 1 : 0));
+  if (e != hipSuccess || b.type != hipMemoryTypeDevice || b.device != device) {
+    (void)hipGetLastError();
+    return fail(nullptr, JB_ERR_GEOMETRY, "the region of %zu bytes reaches beyond its device allocation", bytes);
+  }
+  return JB_OK;
+}
+
 int jb_bind_thread_near_device_(int device) {
   const char *knob = getenv("JPEGBLK_NUMA");
   if (knob && knob[0] == '0') return 0;

@@ -45,6 +45,8 @@ void *jb_wait_begin_(jb_ctx *ctx, int ticket);
 int jb_wait_block_(jb_ctx *ctx, void *event);
 // binds the calling thread to the CPUs of the NUMA node closest to a device (jb_api.cpp)
 int jb_bind_thread_near_device_(int device);
+// JB_OK when [p, p + bytes) is device memory of `device` (jb_api.cpp)
+int jb_check_device_region_(int device, const void *p, size_t bytes);
 
 namespace {
 
@@ -833,7 +835,9 @@ extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_b
     return jb_fail_(nullptr, JB_ERR_UNSUPPORTED, "jb_batch_decoder_set_device_output: a multi-device decoder takes one region per device (jb_batch_decoder_set_device_outputs)");
   if ((d_base == nullptr) != (bytes == 0)) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: pointer and size must both be given or both be zero");
   if ((uintptr_t)d_base & 255) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_output: the region must be 256-byte aligned");
-  int rc = jb_batch_decoder_set_arena(d, 0);  // releases a pinned arena, forgets an earlier device region
+  int rc = d_base ? jb_check_device_region_(d->device, d_base, bytes) : (int)JB_OK;
+  if (rc != JB_OK) return rc;
+  rc = jb_batch_decoder_set_arena(d, 0);  // releases a pinned arena, forgets an earlier device region
   if (rc != JB_OK) return rc;
   if (d_base) {
     d->own_arena.base = (uint8_t *)d_base;
@@ -859,7 +863,10 @@ extern "C" int jb_batch_decoder_set_device_outputs(jb_batch_decoder *d, void *co
     for (int k = 0; k < n; k++)
       if (!d_bases[k] || !bytes[k] || ((uintptr_t)d_bases[k] & 255))
         return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: every region needs a 256-byte aligned pointer and a size");
-  int rc = jb_batch_decoder_set_arena(d, 0);  // a shared pinned arena and device regions exclude each other
+  int rc = JB_OK;
+  for (int k = 0; !off && k < n && rc == JB_OK; k++) rc = jb_check_device_region_(d->parts[(size_t)k]->device, d_bases[k], bytes[k]);
+  if (rc != JB_OK) return rc;
+  rc = jb_batch_decoder_set_arena(d, 0);  // a shared pinned arena and device regions exclude each other
   if (rc != JB_OK) return rc;
   for (size_t k = 0; k < d->parts.size(); k++) {
     jb_batch_decoder *part = d->parts[k];

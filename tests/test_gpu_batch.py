@@ -314,6 +314,13 @@ def test_batch_decoder_device_resident_output(jb, oracle, tmp_path, monkeypatch,
                 assert np.array_equal(got, want[i]), p
         with pytest.raises(AssertionError):
             dec.run(paths)                                       # (the Python wrapper refuses to read device pointers as host memory)
+        # what is not device memory of the decoder's device is refused when it is set, not when a kernel faults
+        host = np.zeros(1 << 20, np.uint8)
+        with pytest.raises(jb.JbError):
+            dec.set_device_output(host.ctypes.data & ~255, 1 << 16)
+        with pytest.raises(jb.JbError):
+            dec.set_device_output(region.data_ptr(), region.numel() + (1 << 40))   # reaches beyond the allocation
+        dec.set_device_output(region.data_ptr(), region.numel())
         # too small a region: the images that do not fit fail with JB_ERR_CAPACITY, the others are right
         small = torch.zeros(2 << 20, dtype=torch.uint8, device="cuda:0")
         dec.set_device_output(small.data_ptr(), small.numel())
