@@ -392,16 +392,17 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   *rgb = nullptr;
   // The entropy stage of a baseline file can run on the device too (jb_huff.hip): the host then only
   // parses the headers and removes the byte stuffing.  One image is one latency-bound submission
-  // (a dozen and a half launches: about 1.3 ms whatever the size, then ~0.4 ms per megabyte of scan)
+  // (a dozen and a half launches: about 1 ms whatever the size, then ~0.4 ms per megabyte of scan)
   // against 5.5 ms per megabyte on one host core, so by default the device takes files of
-  // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.2-1.7 ms against 0.7 on the
-  // host, 1920x1080 4:4:4 (760 KB) 1.0 against 4.0, 8192x8192 4:2:0 (17 MB) 8.5 against 93
+  // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.1-1.4 ms against 0.7 on the
+  // host, 1024x768 4:2:0 (204 KB) 1.37 against 1.21, 1280x720 4:2:0 (238 KB) 1.19 against 1.37,
+  // 1920x1080 4:4:4 (760 KB) 1.0 against 4.0, 8192x8192 4:2:0 (17 MB) 8.5 against 93
   // (tools/single_latency.py).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
   // =1: the device for every file with 16 restart intervals / chunks or more; =2: also fewer intervals.
   // Whatever the device decoder does not take or flags as corrupt goes through the host decoder
   // below, which gives the precise answer.
   {
-    constexpr size_t kAutoDeviceScan = (size_t)384 << 10;
+    constexpr size_t kAutoDeviceScan = (size_t)256 << 10;
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
     const bool forced = knob && (knob[0] == '1' || knob[0] == '2');
     const bool automatic = !knob || (knob[0] != '0' && !forced);

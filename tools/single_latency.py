@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--sub", default="", help="444 | 420: just this sampling")
     ap.add_argument("--dri", default="0,1", help="restart interval in MCU rows, comma separated (0 = none)")
     args = ap.parse_args()
-    sizes = [(679, 451, "420"), (1920, 1080, "444"), (1920, 1080, "420"), (4096, 4096, "420"), (4096, 4096, "444"), (8192, 8192, "420")]
+    sizes = [(679, 451, "420"), (1024, 768, "420"), (1280, 720, "420"), (1280, 720, "444"), (1920, 1080, "444"), (1920, 1080, "420"), (4096, 4096, "420"), (4096, 4096, "444"), (8192, 8192, "420")]
     if args.only:
         sizes = [x for x in sizes if f"{x[0]}x{x[1]}" == args.only]
     if args.sub:
