@@ -14,13 +14,13 @@
 // against the reference's coefficient dumps
 // (images/img4.jpg has DRI = 100) and against the host decoder on writer- and libjpeg-made files.
 //
-// Work decomposition: a workgroup = 128 lanes = 128 consecutive intervals of one image.
+// Work decomposition: a workgroup = 256 lanes = 256 consecutive intervals of one image.
 //   LDS: the image's table set (18 KiB: an 11-bit code table per AC / DC slot + canonical arrays for
 //   longer codes) + a 64-byte ring of upcoming stream bytes per lane (16 KiB): four workgroups per CU.
 //   Every lane walks its own interval as a state machine, one symbol per step (DC and AC symbols
 //   are the same step); lanes are not held together at block boundaries, so a wave takes as many
-//   steps as its longest interval has symbols.  The host zeroes the coefficient area (one memset
-//   per submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
+//   steps as its longest interval has symbols.  The coefficient area is zeroed first (one kernel per
+//   submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
 //   into its block's 128-byte line -- the layout is the fused pixel kernel's input.
 //   The bit stream is read through a 3-dword register window per lane (two dwords in use, one
 //   ahead) fed from the lane's LDS ring, which is topped up from HBM every 4 steps (struct Stream);
