@@ -229,7 +229,7 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
  * synchronise); environment JPEGBLK_GPU_HUFFMAN=0 keeps the entropy stage on the host threads
  * (north_star's split), =2 drops the size threshold.  The single-image jb_decode_file /
  * jb_decode_memory take it for files with 256 KB of entropy-coded data or more, where one image's
- * latency is lower on the device (1920x1080 4:4:4: 1.0 ms against 4.0 ms on one host core;
+ * latency is lower on the device (1920x1080 4:4:4: 0.84 ms against 3.9 ms on one host core;
  * 679x451: 1.2-1.7 against 0.7), with JPEGBLK_GPU_HUFFMAN=1 or 2 for every file the device decoders
  * take, with =0 never.  Files with restart intervals: one lane per interval when the intervals are
  * short, else -- like files without DRI -- one lane per 256-byte chunk of every interval. */

@@ -602,7 +602,10 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
   // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
   static const int env_rounds = getenv("JPEGBLK_SYNC_ROUNDS") ? atoi(getenv("JPEGBLK_SYNC_ROUNDS")) : 0;
-  p.sync_rounds = (env_rounds > 0 && sync_rounds == kJbSyncRounds) ? env_rounds : sync_rounds;
+  // (correct states travel one chunk per pass: half the chunk size, up to twice the passes -- the ones after
+  // convergence cost 5 us each)
+  const int default_rounds = lay.min_chunk_bytes < kJbChunkBytes ? kJbSyncRounds * 3 / 2 : kJbSyncRounds;
+  p.sync_rounds = sync_rounds != kJbSyncRounds ? sync_rounds : env_rounds > 0 ? env_rounds : default_rounds;
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
 }
@@ -1085,6 +1088,7 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   lay->n_wg = (int)n_wg;
   lay->n_sync_wg = (int)n_sync_wg;
   lay->n_sync_images = (int)n_sync_images;
+  lay->min_chunk_bytes = kJbChunkBytes;
   lay->coef_stride = coef_stride;
   if (lay->device_total > 0xffffff00u || n_wg > 0x7fffffffu || n_sync_wg > 0x7fffffffu) return JB_ERR_CAPACITY;
   JbHuffImage *im = (JbHuffImage *)(h + lay->off_img);
@@ -1109,12 +1113,13 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
       JbChunkDesc *cd = (JbChunkDesc *)(h + lay->off_chunks) + chunk0;
       uint32_t c = 0;
       for (uint32_t seg = 0; seg + 1 < (uint32_t)j.starts.size(); seg++) {
-        const uint32_t k = jb_chunks_of_(j.starts[seg + 1] - j.starts[seg]);
+        const uint32_t k = jb_chunks_of_(j.starts[seg + 1] - j.starts[seg], j.img.chunk_bytes);
         if (c + k > j.img.n_chunks) return JB_ERR_STATE;
-        for (uint32_t q = 0; q < k; q++) cd[c++] = JbChunkDesc{j.starts[seg] + q * kJbChunkBytes, seg | (q == 0 ? 0x80000000u : 0u)};
+        for (uint32_t q = 0; q < k; q++) cd[c++] = JbChunkDesc{j.starts[seg] + q * j.img.chunk_bytes, seg | (q == 0 ? 0x80000000u : 0u)};
       }
       if (c != j.img.n_chunks) return JB_ERR_STATE;
       chunk0 += j.img.n_chunks;
+      if (j.img.chunk_bytes < lay->min_chunk_bytes) lay->min_chunk_bytes = j.img.chunk_bytes;
       simg[sn++] = (uint32_t)i;
       for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) swg[sw++] = JbHuffWg{(uint32_t)i, f};
     }

@@ -335,16 +335,24 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   if (ri > 0)
     if (const char *m = getenv("JPEGBLK_HUFF_MODE")) chunked = m[0] == 'c' ? true : m[0] == 'i' ? false : chunked;
   job->img.n_chunks = 0;
+  // A pass over the chunks takes as long as one chunk takes, so small scans -- one image's latency, and
+  // nowhere near filling the device with lanes -- get smaller chunks (JPEGBLK_CHUNK_BYTES = 64 | 128 | 256 forces)
+  uint32_t chunk_bytes = job->scan_len <= ((size_t)2 << 20) ? 128u : kJbChunkBytes;
+  if (const char *e = getenv("JPEGBLK_CHUNK_BYTES")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) chunk_bytes = (uint32_t)v;
+  }
+  job->img.chunk_bytes = chunk_bytes;
   if (chunked) {
     uint64_t n_chunks = 0;
     for (size_t i = 0; i + 1 < job->starts.size(); i++) {
       if (job->starts[i + 1] < job->starts[i]) return done(JB_ERR_FORMAT, "restart intervals out of order");
-      n_chunks += jb_chunks_of_(job->starts[i + 1] - job->starts[i]);
+      n_chunks += jb_chunks_of_(job->starts[i + 1] - job->starts[i], chunk_bytes);
     }
     if (n_chunks > 0x3fffffffu) return done(JB_ERR_UNSUPPORTED, "scan too large for the device decoder: host decoder");
     job->img.n_chunks = (uint32_t)n_chunks;
   }
-  job->img.state_off = job->img.reserved = 0;
+  job->img.state_off = 0;
   if (ri == 0 && job->scan_len == 0) return done(JB_ERR_FORMAT, "empty scan");
   return done(JB_OK, "");
 }
@@ -396,7 +404,7 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   // against 5.5 ms per megabyte on one host core, so by default the device takes files of
   // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.1-1.4 ms against 0.7 on the
   // host, 1024x768 4:2:0 (204 KB) 1.37 against 1.21, 1280x720 4:2:0 (238 KB) 1.19 against 1.37,
-  // 1920x1080 4:4:4 (760 KB) 1.0 against 4.0, 8192x8192 4:2:0 (17 MB) 8.5 against 93
+  // 1920x1080 4:4:4 (760 KB) 0.84 against 3.9, 8192x8192 4:2:0 (17 MB) 8.2 against 92
   // (tools/single_latency.py).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
   // =1: the device for every file with 16 restart intervals / chunks or more; =2: also fewer intervals.
   // Whatever the device decoder does not take or flags as corrupt goes through the host decoder

@@ -38,7 +38,7 @@ struct JbHuffImage {
   uint32_t n_chunks;   // chunks of the image (0 = the interval decoder is used): per interval ceil(bytes / kJbChunkBytes), at least 1
   uint32_t state_off;  // index of the image's first entry in the chunk descriptor / state / sum / base arrays
   uint32_t n_blocks;   // coded blocks in the image: n_mcus * (ny + 2)
-  uint32_t reserved;
+  uint32_t chunk_bytes; // bytes of clean scan per chunk lane: 64, 128 or kJbChunkBytes (jb_huff_prepare_ chooses)
 };
 
 struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart intervals of one image
@@ -47,13 +47,13 @@ struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive restart int
 };
 
 constexpr uint32_t kJbLongInterval = 1024; // mean bytes per restart interval from which the chunk decoder is used for a file with DRI
-constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder
-constexpr int kJbSyncRounds = 16;        // synchronisation passes before the writing pass (which verifies): the default;
+constexpr uint32_t kJbChunkBytes = 256;  // bytes of clean scan per lane of the self-synchronising decoder, at most (JbHuffImage::chunk_bytes)
+constexpr int kJbSyncRounds = 16;        // synchronisation passes before the writing pass (which verifies): the default (24 with chunks below kJbChunkBytes);
                                          // a lane whose start state did not change since the last pass skips its decode
 
 // Chunks never straddle a restart boundary: interval i is cut into chunks from its own first byte
 // (an empty interval still has one chunk, so that its missing blocks are noticed).
-inline uint32_t jb_chunks_of_(uint32_t interval_bytes) { return interval_bytes ? (interval_bytes + kJbChunkBytes - 1) / kJbChunkBytes : 1u; }
+inline uint32_t jb_chunks_of_(uint32_t interval_bytes, uint32_t chunk_bytes) { return interval_bytes ? (interval_bytes + chunk_bytes - 1) / chunk_bytes : 1u; }
 struct JbChunkDesc {
   uint32_t start;  // first byte of the chunk in the image's clean scan
   uint32_t seg;    // the restart interval it lies in; bit 31: it is the interval's first chunk (its start state is known)
@@ -70,7 +70,7 @@ struct JbChunkState {
 // previous path is remembered at kJbCheckpoints places inside the chunk -- the first symbol boundary
 // at or behind every kJbCheckpointBits bits -- with the counts up to there.
 constexpr uint32_t kJbCheckpointBits = 256;
-constexpr uint32_t kJbCheckpoints = kJbChunkBytes * 8 / kJbCheckpointBits - 1;  // 7 inside a chunk
+constexpr uint32_t kJbCheckpoints = kJbChunkBytes * 8 / kJbCheckpointBits - 1;  // 7 inside a chunk of kJbChunkBytes (fewer in a smaller one)
 struct JbCheckpoint {   // 32 bytes
   uint32_t bitpos, meta;     // as in JbChunkState, without the block count
   uint32_t nblk;             // blocks completed in the chunk before this place
@@ -141,6 +141,7 @@ struct JbHuffLayout {
   // device-only scratch behind the uploaded bytes (chunk states x 2, chunk bases)
   size_t off_sync_wg = 0, off_sync_img = 0, off_chunks = 0, off_state_a = 0, off_state_b = 0, off_state_in = 0, off_cps = 0, off_dcsum = 0, off_base = 0, device_total = 0;
   int n_sync_wg = 0, n_sync_images = 0;
+  uint32_t min_chunk_bytes = kJbChunkBytes;  // the smallest chunk size among the submission's images (smaller chunks: more passes)
 };
 // Is the device decoder worth taking for this image?  Interval decoder: at least `min_intervals`
 // intervals; self-synchronising decoder (no DRI, or long intervals): at least 16 chunks.

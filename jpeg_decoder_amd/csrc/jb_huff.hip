@@ -395,7 +395,7 @@ __device__ __forceinline__ ChunkExtent chunk_extent(const JbHuffLaunch &p, const
   uint32_t seg_end = p.starts[img.int_off + x.seg + 1];
   if (seg_end > img.scan_len) seg_end = img.scan_len;
   uint32_t start = cd.start < seg_end ? cd.start : seg_end;
-  uint32_t end = start + kJbChunkBytes < seg_end ? start + kJbChunkBytes : seg_end;
+  uint32_t end = start + img.chunk_bytes < seg_end ? start + img.chunk_bytes : seg_end;
   x.last = end == seg_end;
   x.start_bit = start * 8u;
   x.end_bit = end * 8u;
@@ -464,8 +464,9 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   // records the state and the counts there; a later pass that arrives at a checkpoint in the state
   // recorded for it has met the path of the chunk's previous decode and stops: what follows is known.
   JbCheckpoint *const cps = p.cps + (size_t)(img.state_off + (active ? ci : 0u)) * 8u;
+  const uint32_t n_cp = img.chunk_bytes * 8u / kJbCheckpointBits - 1u;  // checkpoints inside a chunk of this image
   uint32_t cp_i = 0, next_b = nominal_start + kJbCheckpointBits;
-  while (next_b <= bit && cp_i < kJbCheckpoints) {  // a start behind the chunk's first checkpoints (a lane far out of step):
+  while (next_b <= bit && cp_i < n_cp) {  // a start behind the chunk's first checkpoints (a lane far out of step):
     if (live) ((uint4 *)(cps + cp_i))[0] = make_uint4(0xffffffffu, 0u, 0u, 0u);  // what they hold is no longer on this chunk's path
     cp_i++;
     next_b += kJbCheckpointBits;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       }
       const uint32_t bp = (uint32_t)s.bitpos();
       live = bp < end_bit;
-      if (bp >= next_b && cp_i < kJbCheckpoints) {  // rare: at most kJbCheckpoints times per chunk
+      if (bp >= next_b && cp_i < n_cp) {  // rare: at most n_cp times per chunk
         const uint32_t meta = st.k | (st.blk << 8);
         uint4 *rec = (uint4 *)(cps + cp_i);
         if (round > 0 && live) {
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       const uint4 old_sum = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
       const uint4 a = ((const uint4 *)(cps + met_at))[0], b = ((const uint4 *)(cps + met_at))[1];
       const uint32_t d_n = st.nblk - a.z, d0 = dc0 - a.w, d1 = dc1 - b.x, d2 = dc2 - b.y;
-      for (uint32_t i = met_at; i < kJbCheckpoints; i++) {
+      for (uint32_t i = met_at; i < n_cp; i++) {
         uint4 *rec = (uint4 *)(cps + i);
         const uint4 r0 = rec[0], r1 = rec[1];
         rec[0] = make_uint4(r0.x, r0.y, r0.z + d_n, r0.w + d0);
