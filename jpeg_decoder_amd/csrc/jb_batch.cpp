@@ -710,19 +710,19 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   }
   if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
   if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
-  // With the entropy stage on the device (JPEGBLK_GPU_HUFFMAN) a group should be LARGE: an image is
-  // only as many lanes as it has restart intervals, each a long serial decode, and a launch takes
-  // that long whatever the group size -- measured on 1,024 PIL 1080p files: 2,626 images/s in groups
-  // of 20, 3,947 in groups of 64.  The ring slots are sized for a thread's whole share of the batch,
-  // up to JPEGBLK_DEV_GROUP_MB (default 512); the threads' pinned buffers keep their size.
+  // Groups whose entropy stage runs on the device hold about 100 MB of coefficients (JPEGBLK_DEV_GROUP_MB;
+  // 8 1080p images, one 8192x8192 image, at most 64 images).  (With the first versions of the device decoder,
+  // whose launches took milliseconds whatever their size, large groups paid -- 2,626 images/s in groups of
+  // 20, 3,947 in groups of 64 -- and the default was a thread's whole share up to 512 MB.  With today's
+  // kernels many small groups in flight are as fast or faster with host output (medians of six runs:
+  // 0.171 s against 0.18 s for 1,024 1080p files; 8192x8192 +5 %) and much faster with device-resident
+  // output, and the ring slots are a fifth of the size: profiles/r02b/ab_group_size_final.txt.)
   size_t ring_bytes = 0;
   {
     const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
     if (!(knob && knob[0] == '0')) {
       const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
-      // (device-resident output: nothing is downloaded, a group costs its launches' latency, and many small
-      // groups in flight beat few large ones -- about 100 MB of coefficients each: 8 1080p images, one 8192x8192)
-      const long mb = e ? atol(e) : (d->arena->base && d->arena->on_device) ? 96 : 512;
+      const long mb = e ? atol(e) : 96;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
       size_t share = (size_t)((n_paths + n_threads - 1) / (n_threads > 0 ? n_threads : 1));
       if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;
