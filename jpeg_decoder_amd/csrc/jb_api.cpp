@@ -554,7 +554,7 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // upload a packed submission (jb_huff_pack_) and launch the decoder: image i's coefficient blocks
 // land at d_out + i * coef_stride bytes, its status word at s.d_status[i]
 int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up,
-               int sync_rounds = kJbSyncRounds) {
+               int sync_launches = kJbSyncLaunches) {
   if (lay.device_total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
     if (s.d_blob) (void)hipFree(s.d_blob);
     s.d_blob = nullptr, s.blob_cap = 0;
@@ -566,46 +566,38 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
     JB_HIP(ctx, hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault));
     JB_HIP(ctx, hipMalloc((void **)&s.d_status, 4 * 256));
   }
-  // (JPEGBLK_HUFF_FETCH=0: always the copy engine; A/B knob)
-  static const bool fetch_by_kernel = !(getenv("JPEGBLK_HUFF_FETCH") && getenv("JPEGBLK_HUFF_FETCH")[0] == '0');
-  if (fetch_by_kernel && lay.total <= ((size_t)4 << 20)) JB_HIP(ctx, jbk_huff_fetch(s.d_blob, h, lay.total, up));
+  // a small submission is fetched from the pinned blob by a kernel: nothing in front of the decoding kernels waits
+  // for a copy engine
+  if (lay.total <= ((size_t)4 << 20)) JB_HIP(ctx, jbk_huff_fetch(s.d_blob, h, lay.total, up));
   else JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, lay.total, hipMemcpyHostToDevice, up));
-  // the decoder stores non-zero coefficients only.  (JPEGBLK_HUFF_ZERO=0: hipMemsetAsync; A/B knob)
-  static const bool zero_by_kernel = !(getenv("JPEGBLK_HUFF_ZERO") && getenv("JPEGBLK_HUFF_ZERO")[0] == '0');
-  if (zero_by_kernel) {
-    JB_HIP(ctx, jbk_huff_zero(s.d_status, 4 * (size_t)lay.n, up));
-    JB_HIP(ctx, jbk_huff_zero(d_out, zero_bytes, up));
-  } else {
-    JB_HIP(ctx, hipMemsetAsync(s.d_status, 0, 4 * (size_t)lay.n, up));
-    JB_HIP(ctx, hipMemsetAsync(d_out, 0, zero_bytes, up));
-  }
+  // the decoder stores non-zero coefficients only
+  JB_HIP(ctx, jbk_huff_zero(s.d_status, 4 * (size_t)lay.n, up));
+  JB_HIP(ctx, jbk_huff_zero(d_out, zero_bytes, up));
   JbHuffLaunch p;
+  memset(&p, 0, sizeof p);
   const uint8_t *d = (const uint8_t *)s.d_blob;
+  uint8_t *dw = (uint8_t *)s.d_blob;
   p.scan = d + lay.off_scan;
   p.starts = (const uint32_t *)(d + lay.off_starts);
   p.tables = (const JbHuffTables *)(d + lay.off_tab);
   p.images = (const JbHuffImage *)(d + lay.off_img);
   p.wgs = (const JbHuffWg *)(d + lay.off_wg);
+  p.sync_wgs = (const JbHuffWg *)(d + lay.off_sync_wg);
   p.coef = d_out;
   p.status = s.d_status;
   p.n_wgs = (int32_t)lay.n_wg;
-  p.sync_wgs = (const JbHuffWg *)(d + lay.off_sync_wg);
   p.n_sync_wgs = (int32_t)lay.n_sync_wg;
-  p.n_sync_images = (int32_t)lay.n_sync_images;
-  p.sync_images = (const uint32_t *)(d + lay.off_sync_img);
-  p.state_a = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_a);
-  p.state_b = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_b);
-  p.state_in = (JbChunkState *)((uint8_t *)s.d_blob + lay.off_state_in);
   p.chunks = (const JbChunkDesc *)(d + lay.off_chunks);
-  p.cps = (JbCheckpoint *)((uint8_t *)s.d_blob + lay.off_cps);
-  p.dcsum = (uint32_t *)((uint8_t *)s.d_blob + lay.off_dcsum);
-  p.base = (uint32_t *)((uint8_t *)s.d_blob + lay.off_base);
-  // JPEGBLK_SYNC_ROUNDS=N (experiment knob): the number of synchronisation passes of the first attempt
-  static const int env_rounds = getenv("JPEGBLK_SYNC_ROUNDS") ? atoi(getenv("JPEGBLK_SYNC_ROUNDS")) : 0;
-  // (correct states travel one chunk per pass: half the chunk size, up to twice the passes -- the ones after
-  // convergence cost 5 us each)
-  const int default_rounds = lay.min_chunk_bytes < kJbChunkBytes ? kJbSyncRounds * 3 / 2 : kJbSyncRounds;
-  p.sync_rounds = sync_rounds != kJbSyncRounds ? sync_rounds : env_rounds > 0 ? env_rounds : default_rounds;
+  p.entry = (JbChunkState *)(dw + lay.off_entry);
+  p.exit = (JbChunkState *)(dw + lay.off_exit);
+  p.cps = (JbCheckpoint *)(dw + lay.off_cps);
+  p.dcsum = (uint32_t *)(dw + lay.off_dcsum);
+  p.wgsum = (JbWgSum *)(dw + lay.off_wgsum);
+  p.n_chunks_total = lay.n_chunks;
+  // (one workgroup per image: its first chunk starts an interval, nothing to hand over between launches)
+  p.sync_launches = lay.n_sync_wg > 0 && lay.n_wg == lay.n ? 1 : sync_launches;
+  p.max_chunk_bytes = lay.max_chunk_bytes;
+  p.max_tabs = lay.max_tabs;
   JB_HIP(ctx, jbk_huff_launch(p, up));
   return JB_OK;
 }
@@ -768,20 +760,20 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
   JbHuffLayout lay;
   rc = pack_into_slot(ctx, s, jobs, 1, job->geo.coef_bytes, &lay);
   const size_t coef_bytes = (size_t)job->geo.coef_bytes;
-  const int n_chunks = (int)job->img.n_chunks;
   delete job;  // (everything it held is in the pinned blob now)
   if (rc) return rc;
-  // Scans without restart intervals: the chunk lanes fall into step within a few passes on ordinary
-  // data; dense adversarial data (hardly any EOB to meet at) can take more -- status bit 2 says "not
-  // yet", and correct states spread by at least one chunk per pass, so n_chunks passes always do.
-  int rounds = kJbSyncRounds;
+  // The chunks fall into step within the launches of the first attempt on ordinary data; dense adversarial data
+  // (hardly any EOB to meet at) can need a workgroup's state handed on more often -- status bit 2 alone says "not
+  // yet": one retry with more launches, then the caller is told (JB_ERR_FORMAT) and the host decoder
+  // (jb_entropy_decode) is the authority.  Corrupt data (bits 0, 1) is never retried.
+  int launches = kJbSyncLaunches;
   for (;;) {
-    rc = huff_stage(ctx, s, s.h_blob, lay, coef_bytes, d_coef, ctx->stream, rounds);
+    rc = huff_stage(ctx, s, s.h_blob, lay, coef_bytes, d_coef, ctx->stream, launches);
     if (rc) return rc;
     JB_HIP(ctx, hipMemcpyAsync(s.h_status, s.d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
     JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!(s.h_status[0] & 4u) || rounds > n_chunks) break;
-    rounds = rounds < 128 ? 128 : n_chunks + 1;
+    if (s.h_status[0] != 4u || launches >= kJbSyncLaunchesMax) break;
+    launches = kJbSyncLaunchesMax;
   }
   s.n_status = 1;
   return check_status(ctx, s);
@@ -1027,76 +1019,71 @@ int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%
 
 // ---- packing of device-entropy submissions: pure host code (see jb_huff.h) ----------------------
 size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n) {
-  size_t n_wg = 0, n_starts = 0, scan_bytes = 0;
+  size_t n_wg = 0, n_starts = 0, scan_bytes = 0, n_chunks = 0;
   for (int i = 0; i < n; i++) {
-    n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_chunks += jobs[i]->img.n_chunks;
     n_starts += jobs[i]->starts.size();
     scan_bytes += ((jobs[i]->scan.size() + 15) & ~(size_t)15);
   }
-  // (the self-synchronising decoder's lists: a workgroup per kJbHuffLanes chunks, an index per image, a descriptor per chunk)
-  size_t n_sync_wg = 0, n_chunks = 0;
-  for (int i = 0; i < n; i++) {
-    n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
-    n_chunks += jobs[i]->img.n_chunks;
-  }
-  return (size_t)n * sizeof(JbHuffImage) + (n_wg + n_sync_wg) * sizeof(JbHuffWg) + (size_t)n * (sizeof(JbHuffTables) + 4) + n_starts * 4 +
-         n_chunks * sizeof(JbChunkDesc) + scan_bytes + 160;
+  // (every workgroup twice: the list of all of them and the list of the ones that synchronise)
+  return (size_t)n * sizeof(JbHuffImage) + 2 * n_wg * sizeof(JbHuffWg) + (size_t)n * sizeof(JbHuffTables) + n_starts * 4 +
+         n_chunks * sizeof(JbChunkDesc) + scan_bytes + 512;
 }
 
 int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint8_t *h, JbHuffLayout *lay) {
   auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   std::vector<int> set_of((size_t)n, 0);
   std::vector<int> sets;  // index of the first job that owns each distinct table set
-  size_t n_wg = 0, n_starts = 0, scan_bytes = 0, n_sync_wg = 0, n_sync_images = 0, n_chunks = 0;
+  size_t n_wg = 0, n_sync_wg = 0, n_starts = 0, scan_bytes = 0, n_chunks = 0;
+  lay->max_chunk_bytes = 0;
+  lay->max_tabs = 0;
   for (int i = 0; i < n; i++) {
     int found = -1;
     for (size_t k = 0; k < sets.size() && found < 0; k++)
-      if (memcmp(&jobs[sets[k]]->tables, &jobs[i]->tables, sizeof(JbHuffTables)) == 0) found = (int)k;
+      if (jobs[sets[k]]->n_tabs == jobs[i]->n_tabs && memcmp(&jobs[sets[k]]->tables, &jobs[i]->tables, sizeof(JbHuffTables)) == 0) found = (int)k;
     if (found < 0) {
       found = (int)sets.size();
       sets.push_back(i);
     }
     set_of[(size_t)i] = found;
-    if (jobs[i]->img.n_chunks == 0) n_wg += (jobs[i]->img.n_int + kJbHuffLanes - 1) / kJbHuffLanes;
-    else {
-      n_sync_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
-      n_sync_images++;
-      n_chunks += jobs[i]->img.n_chunks;
-    }
+    const size_t wgs = (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_wg += wgs;
+    if (jobs[i]->img.needs_sync) n_sync_wg += wgs;
+    n_chunks += jobs[i]->img.n_chunks;
     n_starts += jobs[i]->starts.size();
     scan_bytes += a16(jobs[i]->scan.size());
-    if (n > 1 && (int64_t)jobs[i]->geo.coef_bytes > coef_stride) return JB_ERR_CAPACITY;
+    if (jobs[i]->img.chunk_bytes > lay->max_chunk_bytes) lay->max_chunk_bytes = jobs[i]->img.chunk_bytes;
+    if (jobs[i]->n_tabs > lay->max_tabs) lay->max_tabs = jobs[i]->n_tabs;
+    // (a frame that changed between the passes of a batch decoder must not write beyond its slot)
+    if ((int64_t)jobs[i]->geo.coef_bytes > coef_stride) return JB_ERR_CAPACITY;
   }
   lay->off_img = 0;
   lay->off_wg = a16((size_t)n * sizeof(JbHuffImage));
-  lay->off_tab = a16(lay->off_wg + n_wg * sizeof(JbHuffWg));
+  lay->off_sync_wg = a16(lay->off_wg + n_wg * sizeof(JbHuffWg));
+  lay->off_tab = a16(lay->off_sync_wg + n_sync_wg * sizeof(JbHuffWg));
   lay->off_starts = lay->off_tab + sets.size() * sizeof(JbHuffTables);
-  lay->off_sync_wg = a16(lay->off_starts + n_starts * 4);
-  lay->off_sync_img = a16(lay->off_sync_wg + n_sync_wg * sizeof(JbHuffWg));
-  lay->off_chunks = a16(lay->off_sync_img + n_sync_images * 4);
+  lay->off_chunks = a16(lay->off_starts + n_starts * 4);
   lay->off_scan = a16(lay->off_chunks + n_chunks * sizeof(JbChunkDesc));
-  lay->total = lay->off_scan + scan_bytes;
+  lay->total = lay->off_scan + scan_bytes + 256;  // (a lane reads up to 16 dwords beyond its chunk's last byte)
   // device-only scratch behind the uploaded bytes
-  lay->off_state_a = a16(lay->total);
-  lay->off_state_b = a16(lay->off_state_a + n_chunks * sizeof(JbChunkState));
-  lay->off_state_in = a16(lay->off_state_b + n_chunks * sizeof(JbChunkState));
-  lay->off_cps = (a16(lay->off_state_in + n_chunks * sizeof(JbChunkState)) + 31) & ~(size_t)31;
-  lay->off_dcsum = a16(lay->off_cps + n_chunks * 8 * sizeof(JbCheckpoint));
-  lay->off_base = a16(lay->off_dcsum + n_chunks * 16);
-  lay->device_total = a16(lay->off_base + n_chunks * 16);
+  lay->off_entry = a16(lay->total);
+  lay->off_exit = a16(lay->off_entry + n_chunks * sizeof(JbChunkState));
+  lay->off_cps = a16(lay->off_exit + n_chunks * sizeof(JbChunkState));
+  lay->off_dcsum = a16(lay->off_cps + n_chunks * kJbCheckpoints * sizeof(JbCheckpoint));
+  lay->off_wgsum = (a16(lay->off_dcsum + n_chunks * 16) + 31) & ~(size_t)31;
+  lay->device_total = a16(lay->off_wgsum + n_wg * sizeof(JbWgSum));
   lay->n = n;
   lay->n_wg = (int)n_wg;
   lay->n_sync_wg = (int)n_sync_wg;
-  lay->n_sync_images = (int)n_sync_images;
-  lay->min_chunk_bytes = kJbChunkBytes;
+  lay->n_chunks = (uint32_t)n_chunks;
   lay->coef_stride = coef_stride;
-  if (lay->device_total > 0xffffff00u || n_wg > 0x7fffffffu || n_sync_wg > 0x7fffffffu) return JB_ERR_CAPACITY;
+  if (lay->device_total > 0xffffff00u || n_wg > 0x7fffffffu || n_chunks > 0x3fffffffu) return JB_ERR_CAPACITY;
   JbHuffImage *im = (JbHuffImage *)(h + lay->off_img);
   JbHuffWg *wg = (JbHuffWg *)(h + lay->off_wg);
   JbHuffWg *swg = (JbHuffWg *)(h + lay->off_sync_wg);
-  uint32_t *simg = (uint32_t *)(h + lay->off_sync_img);
   uint32_t *st = (uint32_t *)(h + lay->off_starts);
-  size_t w = 0, si = 0, sc = lay->off_scan, sw = 0, sn = 0, chunk0 = 0;
+  size_t w = 0, sw = 0, si = 0, sc = lay->off_scan, chunk0 = 0;
   for (size_t k = 0; k < sets.size(); k++) memcpy(h + lay->off_tab + k * sizeof(JbHuffTables), &jobs[sets[k]]->tables, sizeof(JbHuffTables));
   for (int i = 0; i < n; i++) {
     const JbHuffJob &j = *jobs[i];
@@ -1105,28 +1092,27 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
     im[i].int_off = (uint32_t)si;
     im[i].table_set = (uint32_t)set_of[(size_t)i];
     im[i].coef_off = (int64_t)i * coef_stride;
-    if (j.img.n_chunks == 0) {
-      for (uint32_t f = 0; f < j.img.n_int; f += kJbHuffLanes) wg[w++] = JbHuffWg{(uint32_t)i, f};
-    } else {
-      im[i].state_off = (uint32_t)chunk0;
-      // the chunks of every restart interval, from the interval's first byte (jb_chunks_of_)
-      JbChunkDesc *cd = (JbChunkDesc *)(h + lay->off_chunks) + chunk0;
-      uint32_t c = 0;
-      for (uint32_t seg = 0; seg + 1 < (uint32_t)j.starts.size(); seg++) {
-        const uint32_t k = jb_chunks_of_(j.starts[seg + 1] - j.starts[seg], j.img.chunk_bytes);
-        if (c + k > j.img.n_chunks) return JB_ERR_STATE;
-        for (uint32_t q = 0; q < k; q++) cd[c++] = JbChunkDesc{j.starts[seg] + q * j.img.chunk_bytes, seg | (q == 0 ? 0x80000000u : 0u)};
-      }
-      if (c != j.img.n_chunks) return JB_ERR_STATE;
-      chunk0 += j.img.n_chunks;
-      if (j.img.chunk_bytes < lay->min_chunk_bytes) lay->min_chunk_bytes = j.img.chunk_bytes;
-      simg[sn++] = (uint32_t)i;
-      for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) swg[sw++] = JbHuffWg{(uint32_t)i, f};
+    im[i].state_off = (uint32_t)chunk0;
+    im[i].wg0 = (uint32_t)w;
+    // the chunks of every restart interval, from the interval's first byte (jb_chunks_of_)
+    JbChunkDesc *cd = (JbChunkDesc *)(h + lay->off_chunks) + chunk0;
+    uint32_t c = 0;
+    for (uint32_t seg = 0; seg + 1 < (uint32_t)j.starts.size(); seg++) {
+      const uint32_t k = jb_chunks_of_(j.starts[seg + 1] - j.starts[seg], j.img.chunk_bytes);
+      if (c + k > j.img.n_chunks) return JB_ERR_STATE;
+      for (uint32_t q = 0; q < k; q++) cd[c++] = JbChunkDesc{j.starts[seg] + q * j.img.chunk_bytes, seg | (q == 0 ? 0x80000000u : 0u)};
+    }
+    if (c != j.img.n_chunks) return JB_ERR_STATE;
+    chunk0 += j.img.n_chunks;
+    for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) {
+      wg[w++] = JbHuffWg{(uint32_t)i, f};
+      if (j.img.needs_sync) swg[sw++] = JbHuffWg{(uint32_t)i, f};
     }
     memcpy(st + si, j.starts.data(), j.starts.size() * 4);
     si += j.starts.size();
     memcpy(h + sc, j.scan.data(), j.scan.size());
     sc += a16(j.scan.size());
   }
+  memset(h + sc, 0, 256);
   return JB_OK;
 }

@@ -34,6 +34,7 @@
 #include "jb_entropy.h"
 #include "jb_hostmem.h"
 #include "jb_huff.h"
+#include "jb_huff_core.h"
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
@@ -260,6 +261,10 @@ int report(jb_ctx *ctx, const Err &e) { return jb_fail_(ctx, e.code, e.msg.c_str
 
 }  // namespace
 
+bool jb_huff_fill_table_(const uint8_t counts[17], const uint8_t *symbols, bool is_ac, JbHuffTables *set, uint32_t tix, uint32_t n_tabs, uint32_t *n_t2) {
+  return jb_huff_fill_table_impl_(counts, symbols, is_ac, set, tix, n_tabs, n_t2);
+}
+
 // Ready one image for the device-side entropy decoder (jb_huff.hip): see jb_huff.h.
 int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err) {
   Frame *fr = new Frame();
@@ -276,39 +281,42 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   rc = jb_geometry_of(&fr->desc, &job->geo);
   if (rc != JB_OK) return done(rc, "bad frame geometry");
   const int64_t n_mcus = (int64_t)job->geo.mcus_x * job->geo.mcus_y;
-  // with restart intervals: one lane per interval; without: the self-synchronising decoder, one
-  // lane per 256-byte chunk of the scan (jb_huff.hip)
   const int ri = fr->restart_interval > 0 ? fr->restart_interval : 0;
   const int64_t n_int = ri > 0 ? (n_mcus + ri - 1) / ri : 1;
-  // table slots: the three components may name at most two DC and two AC tables
-  int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1};
+  // the tables in use: a frame's three components name at most three tables of each kind (reference
+  // jpeg.cpp:148-196 reads up to four ids of each kind); AC tables first, then DC
+  int ac_ids[3] = {-1, -1, -1}, dc_ids[3] = {-1, -1, -1}, ac_slot[3], dc_slot[3], n_ac = 0, n_dc = 0;
   for (int c = 0; c < 3; c++) {
     for (int kind = 0; kind < 2; kind++) {
-      int *ids = kind ? ac_ids : dc_ids;
+      int *ids = kind ? ac_ids : dc_ids, &n = kind ? n_ac : n_dc;
       const int id = kind ? fr->ac_id[c] : fr->dc_id[c];
-      int slot = ids[0] == id ? 0 : ids[1] == id ? 1 : -1;
-      if (slot < 0) {
-        slot = ids[0] < 0 ? 0 : ids[1] < 0 ? 1 : -1;
-        if (slot < 0) return done(JB_ERR_UNSUPPORTED, "more than two Huffman tables of one kind in use: host decoder");
-        ids[slot] = id;
-      }
-      (kind ? job->img.ac_slot : job->img.dc_slot)[c] = (uint8_t)slot;
+      int slot = -1;
+      for (int q = 0; q < n; q++)
+        if (ids[q] == id) slot = q;
+      if (slot < 0) ids[slot = n++] = id;
+      (kind ? ac_slot : dc_slot)[c] = slot;
     }
   }
-  job->img.dc_slot[3] = job->img.ac_slot[3] = 0;
+  job->n_tabs = (uint32_t)(n_ac + n_dc);
+  job->img.n_tabs = job->n_tabs;
   memset(&job->tables, 0, sizeof job->tables);
-  for (int slot = 0; slot < 2; slot++) {
-    const HuffTable *t[2] = {dc_ids[slot] >= 0 ? &fr->dc[dc_ids[slot]] : nullptr, ac_ids[slot] >= 0 ? &fr->ac[ac_ids[slot]] : nullptr};
-    for (int kind = 0; kind < 2; kind++) {
-      if (!t[kind]) continue;
-      const int at = 2 * kind + slot;
-      memcpy(job->tables.maxcode[at], t[kind]->maxcode, sizeof t[kind]->maxcode);
-      memcpy(job->tables.valptr[at], t[kind]->valptr, sizeof t[kind]->valptr);
-      memcpy(job->tables.mincode[at], t[kind]->mincode, sizeof t[kind]->mincode);
-      memcpy(job->tables.symbols[at], t[kind]->symbols, 256);
-      // the code (without magnitude bits) that starts each 11-bit window
-      memcpy(kind ? job->tables.acl[slot] : job->tables.dcl[slot], t[kind]->code11, sizeof t[kind]->code11);
+  {
+    uint32_t n_t2 = 0;
+    for (int q = 0; q < n_ac + n_dc; q++) {
+      const bool is_ac = q < n_ac;
+      const HuffTable &t = is_ac ? fr->ac[ac_ids[q]] : fr->dc[dc_ids[q - n_ac]];
+      if (!jb_huff_fill_table_(t.counts, t.symbols, is_ac, &job->tables, (uint32_t)q, job->n_tabs, &n_t2))
+        return done(JB_ERR_UNSUPPORTED, "Huffman tables with more long codes than the device decoder's tables hold: host decoder");
     }
+  }
+  const uint32_t ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
+  job->img.nb = ny + 2;
+  job->img.lut_ac = job->img.lut_dc = job->img.lut_comp = 0;
+  for (uint32_t b = 0; b < job->img.nb; b++) {
+    const uint32_t c = b < ny ? 0u : b - ny + 1u;
+    job->img.lut_ac |= (uint32_t)ac_slot[c] << (4 * b);
+    job->img.lut_dc |= (uint32_t)(n_ac + dc_slot[c]) << (4 * b);
+    job->img.lut_comp |= c << (4 * b);
   }
   static thread_local CleanScan tls_scan;
   CleanScan &cs = tls_scan;
@@ -324,33 +332,31 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   job->img.n_int = (uint32_t)n_int;
   job->img.ri = (uint32_t)(ri > 0 ? ri : n_mcus);
   job->img.n_mcus = (uint32_t)n_mcus;
-  job->img.ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
   job->img.coef_off = 0;
-  job->img.n_blocks = (uint32_t)(n_mcus * (job->img.ny + 2));
-  // Which decoder: one lane per restart interval when the intervals are short (many lanes, one
-  // launch), one lane per 256-byte chunk of every interval when they are long or there is only the
-  // one (a 1080p file with an interval per MCU row: 135 lanes of 720 blocks against 3,000 lanes).
-  // JPEGBLK_HUFF_MODE=interval / chunk forces one for files with DRI (tests, A/B runs).
-  bool chunked = ri == 0 || job->scan_len / (uint64_t)n_int >= kJbLongInterval;
-  if (ri > 0)
-    if (const char *m = getenv("JPEGBLK_HUFF_MODE")) chunked = m[0] == 'c' ? true : m[0] == 'i' ? false : chunked;
-  job->img.n_chunks = 0;
-  // A pass over the chunks takes as long as one chunk takes, so small scans -- one image's latency, and
-  // nowhere near filling the device with lanes -- get smaller chunks (JPEGBLK_CHUNK_BYTES = 64 | 128 | 256 forces)
-  uint32_t chunk_bytes = job->scan_len <= ((size_t)2 << 20) ? 128u : kJbChunkBytes;
+  job->img.blk_bytes = 128;
+  job->img.wg0 = 0;
+  if ((uint64_t)n_mcus * job->img.nb >= (1u << 24)) return done(JB_ERR_UNSUPPORTED, "more blocks than the device decoder's 24-bit block index holds: host decoder");
+  job->img.n_blocks = (uint32_t)(n_mcus * job->img.nb);
+  // Every restart interval (a scan without DRI is one interval) is cut into chunks from its own first byte, one
+  // lane per chunk (jb_huff.h).  JPEGBLK_CHUNK_BYTES = 64 | 128 forces a size (tests, A/B runs).
+  uint32_t chunk_bytes = kJbChunkBytes;
   if (const char *e = getenv("JPEGBLK_CHUNK_BYTES")) {
     const int v = atoi(e);
-    if (v == 64 || v == 128 || v == 256) chunk_bytes = (uint32_t)v;
+    if (v == 64 || v == 128) chunk_bytes = (uint32_t)v;
   }
   job->img.chunk_bytes = chunk_bytes;
-  if (chunked) {
+  {
     uint64_t n_chunks = 0;
+    bool needs_sync = false;
     for (size_t i = 0; i + 1 < job->starts.size(); i++) {
       if (job->starts[i + 1] < job->starts[i]) return done(JB_ERR_FORMAT, "restart intervals out of order");
-      n_chunks += jb_chunks_of_(job->starts[i + 1] - job->starts[i], chunk_bytes);
+      const uint32_t k = jb_chunks_of_(job->starts[i + 1] - job->starts[i], chunk_bytes);
+      needs_sync |= k > 1;
+      n_chunks += k;
     }
     if (n_chunks > 0x3fffffffu) return done(JB_ERR_UNSUPPORTED, "scan too large for the device decoder: host decoder");
     job->img.n_chunks = (uint32_t)n_chunks;
+    job->img.needs_sync = needs_sync ? 1u : 0u;
   }
   job->img.state_off = 0;
   if (ri == 0 && job->scan_len == 0) return done(JB_ERR_FORMAT, "empty scan");

@@ -1,679 +1,462 @@
 // jb_huff.hip -- Huffman decoding of baseline scans ON THE DEVICE (gfx950).  Beyond the reference
 // (its decodeHuffman, jpeg.cpp:405-446, is serial host code and north_star keeps the entropy stage
-// on the host): SURVEY.md section 8(f) rank 4.  Files with short restart intervals take the
-// interval decoder below (one lane per interval), files without DRI and files with long intervals
-// the self-synchronising decoder further down (one lane per 256-byte chunk); progressive /
-// grayscale / multi-scan files stay on the host (jb_frontend_ext.cpp).
+// on the host): SURVEY.md section 8(f) rank 4.  Progressive / multi-scan files stay on the host
+// (jb_frontend_ext.cpp).
 //
-// Why it works: the DC predictors reset at every restart marker (T.81 F.2.1.3.1; reference
-// jpeg.cpp:419-425), so the intervals of a scan are independent bit streams -- after the host has
-// removed the byte stuffing and recorded where each interval starts (jbe::unstuff: memchr speed),
-// interval i is "decode ri MCUs from byte start[i]".  A lane does what the host decoder does for
-// one interval -- the same canonical codes (the host front end's 11-bit code table and canonical
-// arrays), the same EXTEND, the same checks -- one symbol per step; tests pin the coefficients
-// against the reference's coefficient dumps
-// (images/img4.jpg has DRI = 100) and against the host decoder on writer- and libjpeg-made files.
+// A Huffman stream can only be decoded from its start -- but a decoder started at a wrong place, in
+// a wrong state, falls into step with the true symbol sequence after a few symbols or blocks and
+// stays in step (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 for JPEG on GPUs).  The DC
+// predictors reset at every restart marker (T.81 F.2.1.3.1; reference jpeg.cpp:419-425), so the
+// restart intervals of a scan are independent streams (a scan without DRI is one interval).  The
+// host removes the byte stuffing and records where each interval starts (jbe::unstuff: memchr
+// speed); every interval is cut into chunks of 128 (small scans: 64) bytes from its own first byte,
+// ONE LANE PER CHUNK, 256 consecutive chunks of one image per workgroup:
 //
-// Work decomposition: a workgroup = 256 lanes = 256 consecutive intervals of one image.
-//   LDS: the image's table set (18 KiB: an 11-bit code table per AC / DC slot + canonical arrays for
-//   longer codes) + a 64-byte ring of upcoming stream bytes per lane (16 KiB): four workgroups per CU.
-//   Every lane walks its own interval as a state machine, one symbol per step (DC and AC symbols
-//   are the same step); lanes are not held together at block boundaries, so a wave takes as many
-//   steps as its longest interval has symbols.  The coefficient area is zeroed first (one kernel per
-//   submission, microseconds); a lane stores its non-zero coefficients, de-zigzagged, straight
-//   into its block's 128-byte line -- the layout is the fused pixel kernel's input.
-//   The bit stream is read through a 3-dword register window per lane (two dwords in use, one
-//   ahead) fed from the lane's LDS ring, which is topped up from HBM every 4 steps (struct Stream);
-//   a symbol consumes at most 27 bits, so the window advances by at most one dword per step.
-// Safety: every stream read is clamped into the image's padded scan; k only grows inside a block
-// (at most 63 iterations); output indices come from host-validated counts.  Corrupt data sets the
-// image's status word and the host re-decodes that image with the serial reader for the precise
-// answer.
+//   synchronisation  jb_huff_sync_kernel.  Pass 0: every lane decodes its chunk from the chunk's first
+//                    bit, assuming "the DC symbol of the MCU's first block is next" (true for the first
+//                    chunk of an interval), and leaves its EXIT state in LDS: the bit at which the first
+//                    symbol of the next chunk starts, the position k in the block, the block's place in
+//                    the MCU -- with the blocks it completed and the DC differences it summed, per
+//                    component.  Pass r > 0, same launch: a lane whose left neighbour's exit state is not
+//                    the state it decoded from decodes again, from there -- and stops as soon as it MEETS
+//                    the path of its previous decode (checkpoints: the first symbol boundary behind every
+//                    256 bits, state in LDS, counts in device memory): from equal (bit, k, block) on
+//                    everything is the same, so the old exit state stands and the counts shift by what
+//                    differed up to the meeting place.  Passes repeat until no lane of the workgroup
+//                    changed: the 256 chunks then are ONE consistent decode from the state the
+//                    workgroup's first lane assumed.  A second launch hands every workgroup the final
+//                    exit state of the chunk before its first and repairs the few chunks that change.
+//   writing pass     jb_huff_write_kernel: segmented prefix sums over the chunks of each interval (the
+//                    workgroups' totals, then a scan inside the workgroup) give every chunk the block it
+//                    starts in (an interval's first block is known: interval x ri x blocks per MCU) and
+//                    the three DC predictors there (0 at an interval's start); every lane decodes its
+//                    chunk once more from its neighbour's final exit state and stores the coefficients,
+//                    the DC ones as running predictors (reference jpeg.cpp:335-345) -- and VERIFIES: the
+//                    state it starts from is the one the synchronisation decoded it from, it ends in the
+//                    exit state recorded for it with the recorded counts, an interval's last chunk ends
+//                    with the interval's last block.  If every lane does, the chain from every true start
+//                    is consistent, i.e. this is the one true decode; if not (corrupt data, or not in step
+//                    yet) the image's status word is set and the host decodes that image.
+//
+// The step (jb_huff_core.h): one symbol, DC and AC alike -- the 32 bits at the lane's position out of
+// two LDS dwords of the transposed chunk (conflict free whatever the lanes' positions), one 16-bit
+// table entry that holds bits consumed, magnitude size and the advance of k, a branch-free EXTEND,
+// branch-free state update.  No memory access but LDS in the synchronisation passes' loop (device
+// memory only where a checkpoint is crossed); the writing pass adds one 2-byte store of the
+// de-zigzagged coefficient straight into the layout the fused pixel kernel reads (the area is
+// zeroed once per submission; the L2 gathers a line's stores).
+// Safety: every position stays inside the lane's rows of LDS (u < u_end <= 32 + 24 + 8 * chunk, a
+// symbol takes at most 27 bits); k only grows inside a block; output indices come from host-validated
+// counts and are checked against the interval's last block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <cstdlib>
 
-#include "jb_huff.h"
+#include "jb_huff_core.h"
 #include "jb_kernels.h"
 
 namespace {
 
+constexpr uint32_t L = kJbhLanes;
+constexpr int kMaxPasses = (int)L + 4;  // correct states travel at least one chunk per pass
 
-constexpr uint32_t kRing = 64;   // bytes of the stream a lane keeps staged in LDS
+// 2 * natural index of zig-zag position i (ITU-T T.81 Figure A.6; reference types.hpp:23-31)
+__constant__ uint8_t kZz2Dev[64] = {0,   2,   16,  32,  18,  4,   6,   20,  34,  48, 64,  50,  36,  22,  8,   10,
+                                    24,  38,  52,  66,  80,  96,  82,  68,  54,  40, 26,  12,  14,  28,  42,  56,
+                                    70,  84,  98,  112, 114, 100, 86,  72,  58,  44, 30,  46,  60,  74,  88,  102,
+                                    116, 118, 104, 90,  76,  62,  78,  92,  106, 120, 122, 108, 94,  110, 124, 126};
 
-// A lane's view of its interval's bit stream.  Bits are taken from a two-dword register window
-// (d0:d1 at bit offset `off`, d2 one dword ahead); the dwords come from a 128-byte ring in LDS that
-// is topped up from HBM in aligned 16-byte chunks every 4 steps -- a wave-uniform point, and the
-// chunk asked for at one such point is written into the ring at the next, so its latency is hidden
-// behind four steps of decoding.  (Fetching per dword from HBM instead put a memory round
-// trip into every iteration of the symbol loop: with 64 lanes in flight some lane crosses a dword
-// in every iteration, and the wave waits for it.)  A block that outruns the ring reads straight
-// from HBM, which is only slower.
-struct Stream {
-  const uint8_t *base;  // the image's clean scan (16-byte aligned)
-  uint32_t limit;       // highest byte offset a 16-byte read may start at (inside the zero padding)
-  uint8_t *ring;        // this lane's ring in LDS
-  uint32_t wr;          // the ring holds stream bytes [wr - kRing, wr); multiple of 16
-  uint32_t pos;         // byte offset of the next dword to fetch into the window
-  uint32_t d0, d1, d2;  // window: bits come from d0:d1 at bit offset `off`; d2 is the next dword
-  uint32_t off;         // 0..31
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t pend0, pend1; // chunks on their way from HBM (asked for at the previous block boundary)
-  uint32_t npend;       // 0..2
-
-  __device__ __forceinline__ u32x4_t chunk(uint32_t at) const { return *(const u32x4_t *)(base + (at < limit ? at : limit)); }
-  // The window is fed from LDS ONLY.  (A fetch with an HBM path in it makes d2 "possibly the result
-  // of a global load", and every use of it then waits for vmcnt(0) -- which on gfx950 also means
-  // every coefficient store issued so far: a memory round trip per iteration of the symbol loop.
-  // Measured: 8.5-16 us per block round with that path, against the ~3 us the LDS latencies allow.)
-  __device__ __forceinline__ uint32_t fetch(uint32_t at) const {
-    return __builtin_bswap32(*(const uint32_t *)(ring + (at & (kRing - 1))));
-  }
-  // A block that outruns the ring (more than ~36 bytes of entropy-coded data in one block) refills
-  // it on the spot: rare, and the only place inside a block that waits for HBM.  Replacing the ring's
-  // oldest chunk is safe here: the window (from pos - 12 on) is at the ring's newest bytes.
-  __device__ __forceinline__ void refill_now() {
-    if (npend >= 1) {
-      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend0;
-      wr += 16;
-    }
-    if (npend >= 2) {
-      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend1;
-      wr += 16;
-    }
-    npend = 0;
-    while (pos + 4 > wr) {
-      *(u32x4_t *)(ring + (wr & (kRing - 1))) = chunk(wr);
-      wr += 16;
-    }
-  }
-  __device__ __forceinline__ void open(uint32_t start) {
-    wr = start & ~15u;
-#pragma unroll
-    for (int i = 0; i < 4; i++) *(u32x4_t *)(ring + ((wr + 16u * i) & (kRing - 1))) = chunk(wr + 16u * i);
-    wr += 64;
-    npend = 0;
-    pos = start & ~3u;
-    off = (start & 3u) * 8u;
-    d0 = fetch(pos);
-    d1 = fetch(pos + 4);
-    d2 = fetch(pos + 8);
-    pos += 12;
-  }
-  // block boundary: what was asked for last time goes into the ring, then ask for what fits now
-  __device__ __forceinline__ void top_up() {
-    if (npend >= 1) {
-      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend0;
-      wr += 16;
-    }
-    if (npend >= 2) {
-      *(u32x4_t *)(ring + (wr & (kRing - 1))) = pend1;
-      wr += 16;
-    }
-    // a chunk may replace ring bytes [wr - kRing, wr - kRing + 16) once the window has moved past them
-    // (the window's first dword is at pos - 12)
-    npend = 0;
-    if (wr + 16 + 12 <= pos + kRing) {
-      pend0 = chunk(wr);
-      npend = 1;
-      if (wr + 32 + 12 <= pos + kRing) {
-        pend1 = chunk(wr + 16);
-        npend = 2;
-      }
-    }
-  }
-  // the next 32 bits of the stream
-  __device__ __forceinline__ uint32_t window() const { return (uint32_t)(((((uint64_t)d0) << 32) | d1) << off >> 32); }
-  // any n <= 32: the window moves by one dword at most
-  __device__ __forceinline__ void consume(uint32_t n) {
-    off += n;
-    if (off >= 32) {
-      off -= 32;
-      d0 = d1;
-      d1 = d2;
-      if (__builtin_expect(pos + 4 > wr, 0)) refill_now();
-      d2 = fetch(pos);
-      pos += 4;
-    }
-  }
-  // bit position in the scan (from its first byte)
-  __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)(pos - 12) * 8 + off; }
+// LDS of a workgroup: the transposed stream, the checkpoint states, the exit states the lanes hand to their
+// right neighbours, 256 bytes of odds and ends, the table set
+template <uint32_t kMaxChunk>
+struct Lay {
+  static constexpr uint32_t kRows = jbh_rows(kMaxChunk);
+  static constexpr uint32_t kNcp = kMaxChunk * 8u / kJbCheckpointBits;  // boundaries a chunk can cross
+  static_assert(kNcp <= kJbCheckpoints, "records per chunk");
+  static constexpr uint32_t off_stream = 0;
+  static constexpr uint32_t off_cp = off_stream + kRows * L * 4u;
+  static constexpr uint32_t off_xbit = off_cp + kNcp * L * 4u;
+  static constexpr uint32_t off_xmeta = off_xbit + L * 4u;
+  static constexpr uint32_t off_misc = off_xmeta + L * 4u;
+  static constexpr uint32_t off_tab = off_misc + 256u;
+  static uint32_t bytes(uint32_t n_tabs) { return off_tab + n_tabs * kJbT1Entries * 2u + kJbT2Tables * kJbT2Entries * 2u; }
 };
 
-__device__ __forceinline__ int extend(uint32_t v, int n) {  // T.81 F.2.2.1 EXTEND; reference jpeg.cpp:340-343
-  return (int)v < (1 << (n - 1)) ? (int)v - (1 << n) + 1 : (int)v;
-}
-
-struct LdsTables {
-  JbHuffTables t;
+struct ChunkGeo {
+  uint32_t start, end;  // the chunk's bytes in the image's clean scan (end: the interval's end at the latest)
+  uint32_t seg;         // its restart interval
+  bool first, last;     // of its interval
 };
-
-// A code of 12..16 bits (the 11-bit window table said "longer"): all five candidate lengths compared
-// at once -- the canonical rule "the first length whose code does not exceed that length's largest
-// code" (reference huffman.hpp:17-29 builds the same codes) -- no loop, because with 64 lanes in
-// flight some lane is here in many iterations and the whole wave walks the path.
-// -> (length << 8) | symbol, or 0 when no code matches.
-__device__ __forceinline__ uint32_t long_code(uint32_t bits, const JbHuffTables &t, int slot) {
-  int len = 17;
-#pragma unroll
-  for (int l = 16; l >= 12; l--)
-    if ((int32_t)(bits >> (32 - l)) <= t.maxcode[slot][l]) len = l;
-  if (len > 16) return 0;
-  const int32_t code = (int32_t)(bits >> (32 - len));
-  return ((uint32_t)len << 8) | t.symbols[slot][(t.valptr[slot][len] + code - t.mincode[slot][len]) & 255];
-}
-
-// Timing experiments (tools/build_huff_variant.sh, never the product; results are wrong with them):
-//   JBH_NO_STORE    no coefficient stores        JBH_NO_TOPUP  the ring is only refilled when it runs dry
-#ifdef JBH_NO_STORE
-#define JBH_STORE(lhs, v) ((void)(v))
-#else
-#define JBH_STORE(lhs, v) ((lhs) = (v))
-#endif
-
-__constant__ uint8_t kZigZagDev[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
-                                       12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
-                                       58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-}  // namespace
-
-__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_kernel(const JbHuffLaunch p) {
-  __shared__ __attribute__((aligned(16))) LdsTables lds;
-  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
-  __shared__ uint8_t zz[64];
-  const int tid = threadIdx.x;
-  const JbHuffWg wg = p.wgs[blockIdx.x];
-  const JbHuffImage img = p.images[wg.image];
-  // the table slots of the three components, packed (a dynamically indexed copy of `img` would be
-  // promoted to LDS by the compiler: 12 KiB per workgroup)
-  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
-                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
-
-  // the image's table set -> LDS (16-byte copies, the struct is a multiple of 16 bytes)
-  {
-    const uint4 *src = (const uint4 *)(p.tables + img.table_set);
-    uint4 *dst = (uint4 *)&lds.t;
-    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst[i] = src[i];
-    if (tid < 64) zz[tid] = kZigZagDev[tid];
-  }
-  __syncthreads();
-
-  const uint32_t iv = wg.first_interval + (uint32_t)tid;
-  const bool active = iv < img.n_int;
-  const uint32_t nb = img.ny + 2;
-  uint32_t count = 0, start = 0, end = 0;
-  if (active) {
-    const uint32_t m0 = iv * img.ri;
-    count = img.n_mcus - m0 < img.ri ? img.n_mcus - m0 : img.ri;
-    start = p.starts[img.int_off + iv];
-    end = p.starts[img.int_off + iv + 1];
-  }
-  Stream s;
-  s.base = p.scan + img.scan_off;
-  s.limit = (img.scan_len + 48u) & ~15u;  // a 16-byte read from here still lies inside the 64 zero bytes behind the data
-  s.ring = rings + tid * kRing;
-  s.open(start);
-
-  // The coefficient area was zeroed by the host's memset before this launch: a lane only stores the
-  // non-zero coefficients, de-zigzagged, straight into its block's 128-byte line; the L2 gathers a
-  // line's stores before the line leaves for HBM.
-  int16_t *out = (int16_t *)((uint8_t *)p.coef + img.coef_off) + (int64_t)iv * img.ri * nb * 64;
-  int pred0 = 0, pred1 = 0, pred2 = 0;
-  uint32_t err = 0;
-
-  // ---- one symbol per step, every lane at its own place in its own interval -------------------
-  // What reference decodeMCUComponent does per block (jpeg.cpp:322-403; same results as the host
-  // decoder's decode_block_clean) as a per-lane state machine: k == 0 means "the DC symbol is next",
-  // 1..63 "an AC symbol for zig-zag position k is next".  Lanes are NOT held together at block
-  // boundaries: a wave then takes as many steps as its longest INTERVAL has symbols (sums of 720
-  // blocks barely differ between lanes), not the sum over block rounds of the longest BLOCK of the
-  // round (a block of 35 symbols among 64 lanes in most rounds, against 11 on average) -- a third
-  // of the steps on a photographic file.  DC and AC symbols are the same step: code from the 11-bit
-  // window table of the lane's current component and kind, magnitude bits out of the same 32-bit
-  // window, one consume, one predicated store.  The ring is topped up every 4 steps, a wave-uniform
-  // point: a lane consumes at most 14 bytes in 4 steps, a top-up asks for up to 32 as soon as fewer
-  // than 37 lie ahead, and what it asks for arrives at the next one -- the ring never runs dry.
-  bool live = active && count > 0;
-  uint32_t blk = 0, mcus_left = count;
-  int k = 0;
-  // (four steps per top-up as an unrolled inner loop: a step counter tested inside the loop body made the
-  // compiler copy the loop-carried registers back and forth in every iteration -- 16 % of a pass)
-  for (;;) {
-    if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // wave-uniform: every lane of this wave is through
-#ifndef JBH_NO_TOPUP
-    if (live) s.top_up();
-#endif
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-    if (live) {
-      const int c = blk < img.ny ? 0 : (int)(blk - img.ny) + 1;
-      const bool isdc = k == 0;
-      const uint32_t slot = (slots >> (isdc ? c : 4 + c)) & 1u;
-      const uint32_t bits = s.window();
-      // acl[2][2048] and dcl[2][2048] lie back to back: one 16-bit read at a per-lane offset
-      uint32_t t = ((const uint16_t *)lds.t.acl)[(isdc ? 4096u : 0u) + slot * 2048u + (bits >> 21)];
-      if (t == 0) t = long_code(bits, lds.t, (int)((isdc ? 0u : 2u) + slot));
-      const uint32_t len = t >> 8, rs = t & 0xffu;
-      const uint32_t sz = isdc ? rs : (rs & 15u);
-      const bool eob = !isdc && rs == 0;
-      const int kk = k + (isdc ? 0 : rs == 0xf0u ? 16 : (int)(rs >> 4));  // (a ZRL, or the run of a run/size symbol)
-      bool bad = t == 0 || (isdc ? sz > 11 : (!eob && (kk > 63 || sz > 10)));  // reference jpeg.cpp:372-385
-      int val = 0;
-      if (sz && !bad) val = extend((bits << len) >> (32 - sz), (int)sz);  // len + sz <= 27 bits of the 32
-      if (isdc) {
-        int pr = (c == 0 ? pred0 : c == 1 ? pred1 : pred2) + val;
-        if (pr < -32768 || pr > 32767) bad = true, pr = 0;
-        if (c == 0) pred0 = pr;
-        else if (c == 1) pred1 = pr;
-        else pred2 = pr;
-        val = pr;
-      }
-      if (!bad && (isdc ? val != 0 : sz != 0)) JBH_STORE(out[zz[kk & 63]], (int16_t)val);
-      if (!bad) s.consume(len + sz);
-      k = isdc ? 1 : eob ? 64 : kk + (sz ? 1 : 0);
-      if (bad) {
-        err |= 1;
-        live = false;  // what follows in this interval is garbage; the host re-decodes the image
-      }
-      if (k > 63) {  // the block is complete: on to the next one of this lane's interval
-        k = 0;
-        out += 64;
-        if (++blk == nb) {
-          blk = 0;
-          if (--mcus_left == 0) live = false;
-        }
-      }
-    }
-  }
-  if (active) {
-    // more bits consumed than the interval holds: truncated or corrupt data
-    if (s.bitpos() > (uint64_t)end * 8) err |= 2;
-    if (err) atomicOr(p.status + wg.image, err);
-  }
-}
-
-// ================================================================================================
-// Scans WITHOUT restart intervals, and scans whose intervals are long: the self-synchronising decoder.
-//
-// A Huffman stream can only be decoded from its start -- but a decoder started at a wrong place,
-// in a wrong state, falls into step with the true symbol sequence after a few symbols or blocks
-// and stays in step from then on.  So every restart interval (a scan without DRI is one interval)
-// is cut into chunks of kJbChunkBytes bytes from its own first byte, one lane per chunk -- a 1080p
-// file with one restart interval per MCU row is 3,000 lanes this way instead of the 135 of the
-// interval decoder above:
-//   sync pass 0      every lane decodes its chunk from the chunk's first bit, assuming "a DC symbol
-//                    of the MCU's first block is next" (true for the first chunk of an interval), and
-//                    records its EXIT state: the bit at which the first symbol of the next chunk
-//                    starts, the position k inside the block, the block's place in the MCU, how many
-//                    blocks it completed -- and the sum of the DC differences it decoded, per component;
-//   sync pass r > 0  every lane decodes its chunk again, now from the exit state its left neighbour
-//                    recorded in pass r - 1 (an interval's first chunk: from the true start).  Correct
-//                    states spread from the interval starts, at least one chunk per pass, in practice
-//                    across a whole scan in a few passes because most lanes had fallen into step inside
-//                    their own chunk already.  A lane whose start state is the one it decoded from in the
-//                    pass before keeps its results and does nothing: passes after convergence cost a launch;
-//   scan             exclusive prefix sums over the chunks of each interval: the block a chunk starts
-//                    in (an interval's first block is known: interval x ri x blocks per MCU) and the
-//                    three DC predictors at its start (0 at an interval's start: T.81 F.2.1.3.1;
-//                    reference jpeg.cpp:419-425);
-//   write pass       every lane decodes its chunk once more from its neighbour's final exit state
-//                    and this time stores the coefficients, the DC ones as running predictors
-//                    (reference jpeg.cpp:335-345) -- and VERIFIES that it ends in the exit state
-//                    recorded for it, an interval's last chunk that it ends with the interval's last
-//                    block: if every lane does, the chain from every true start is consistent, i.e.
-//                    this is the one true decode; if not (not yet synchronised after kJbSyncRounds
-//                    passes, or corrupt data) the image's status word is set and the host decodes
-//                    that image.
-// A step is the same as in the interval decoder above; the tables, the stream ring and the layout
-// of the output are shared.  (Idea: Klein & Wiseman 2003; Weissenberger & Schmidt 2018 for JPEG on GPUs.)
-
-namespace {
-
-struct ChunkLane {
-  uint32_t k, blk, nblk;  // position in the block (0 = DC next), block within the MCU, blocks completed
-};
-// (the three DC values of a lane -- sync passes: sums of the DC differences so far; write pass: the DC
-// predictors -- are separate variables on purpose: as neighbouring fields of the struct the compiler
-// reads them as an array indexed by the component, and puts the struct into scratch memory -- whose
-// set-up costs the first such kernel of a burst 130 us -- or, promoted, into 6 KiB more LDS)
-
-// one symbol; kStore == false: only the state moves (and the DC differences are summed).  Returns
-// false when the data cannot be what the state says (the caller decides what that means).
-template <bool kStore>
-__device__ __forceinline__ bool chunk_step(Stream &s, const JbHuffTables &t, const uint8_t *zz, uint32_t slots, uint32_t ny, uint32_t nb,
-                                           ChunkLane &st, uint32_t &dc0, uint32_t &dc1, uint32_t &dc2, int16_t *block_out) {
-  const int c = st.blk < ny ? 0 : (int)(st.blk - ny) + 1;
-  const bool isdc = st.k == 0;
-  const uint32_t slot = (slots >> (isdc ? c : 4 + c)) & 1u;
-  const uint32_t bits = s.window();
-  uint32_t e = ((const uint16_t *)t.acl)[(isdc ? 4096u : 0u) + slot * 2048u + (bits >> 21)];
-  if (e == 0) e = long_code(bits, t, (int)((isdc ? 0u : 2u) + slot));
-  const uint32_t len = e >> 8, rs = e & 0xffu;
-  const uint32_t sz = isdc ? rs : (rs & 15u);
-  const bool eob = !isdc && rs == 0;
-  const uint32_t kk = st.k + (isdc ? 0u : rs == 0xf0u ? 16u : (rs >> 4));
-  if (e == 0 || (isdc ? sz > 11 : (!eob && (kk > 63 || sz > 10)))) return false;
-  int val = 0;
-  if ((kStore || isdc) && sz) val = extend((bits << len) >> (32 - sz), (int)sz);
-  if (isdc) {
-    // (unsigned: the sums of a lane that is out of step are garbage and may wrap)
-    const uint32_t pr = (c == 0 ? dc0 : c == 1 ? dc1 : dc2) + (uint32_t)val;
-    if (kStore && ((int32_t)pr < -32768 || (int32_t)pr > 32767)) return false;  // a predictor the reference's short cannot hold
-    dc0 = c == 0 ? pr : dc0;
-    dc1 = c == 1 ? pr : dc1;
-    dc2 = c == 2 ? pr : dc2;
-    val = (int32_t)pr;
-  }
-  if (kStore && (isdc ? val != 0 : sz != 0)) JBH_STORE(block_out[zz[kk & 63]], (int16_t)val);
-  s.consume(len + sz);
-  st.k = isdc ? 1u : eob ? 64u : kk + (sz ? 1u : 0u);
-  if (st.k > 63) {
-    st.k = 0;
-    st.nblk++;
-    if (++st.blk == nb) st.blk = 0;
-  }
-  return true;
-}
-
-__device__ __forceinline__ void open_at_bit(Stream &s, uint32_t bit) {
-  s.open(bit >> 3);
-  s.off += bit & 7u;  // (start & 3) * 8 + (bit & 7) <= 31
-}
-
-// where a lane's chunk lies
-struct ChunkExtent {
-  uint32_t start_bit, end_bit;  // the chunk's bits in the image's clean scan (end: the interval's end at the latest)
-  uint32_t seg;                 // its restart interval
-  bool first, last;             // of its interval
-};
-__device__ __forceinline__ ChunkExtent chunk_extent(const JbHuffLaunch &p, const JbHuffImage &img, uint32_t ci) {
-  const JbChunkDesc cd = p.chunks[img.state_off + ci];
-  ChunkExtent x;
+__device__ __forceinline__ ChunkGeo chunk_geo(const JbHuffLaunch &p, const JbHuffImage &img, uint32_t gidx) {
+  const JbChunkDesc cd = p.chunks[gidx];
+  ChunkGeo x;
   x.seg = cd.seg & 0x7fffffffu;
   x.first = (cd.seg >> 31) != 0;
   uint32_t seg_end = p.starts[img.int_off + x.seg + 1];
   if (seg_end > img.scan_len) seg_end = img.scan_len;
-  uint32_t start = cd.start < seg_end ? cd.start : seg_end;
-  uint32_t end = start + img.chunk_bytes < seg_end ? start + img.chunk_bytes : seg_end;
-  x.last = end == seg_end;
-  x.start_bit = start * 8u;
-  x.end_bit = end * 8u;
+  x.start = cd.start < seg_end ? cd.start : seg_end;
+  x.end = x.start + img.chunk_bytes < seg_end ? x.start + img.chunk_bytes : seg_end;
+  x.last = x.end == seg_end;
   return x;
+}
+
+// the lane's rows of the transposed stream: big-endian dwords from byte A = (start & ~3) - 4 of the image's scan
+// (behind the last image's scan lie 64 zero bytes and the submission's device scratch: nothing is read out of bounds)
+template <uint32_t kRows>
+__device__ __forceinline__ void load_stream(uint32_t *stream, const uint8_t *img_scan, uint32_t start, uint32_t tid) {
+  const uint8_t *src = img_scan + (int32_t)jbh_base_byte(start);
+#pragma unroll
+  for (uint32_t q = 0; q < (kRows + 3u) / 4u; q++) {
+    const uint4 v = *(const uint4 *)(src + 16u * q);
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+      if (4u * q + i < kRows) stream[(4u * q + i) * L + tid] = __builtin_bswap32(d[i]);
+  }
+}
+
+__device__ __forceinline__ void load_tables(uint16_t *tab, const JbHuffLaunch &p, const JbHuffImage &img, uint32_t tid) {
+  const JbHuffTables *set = p.tables + img.table_set;
+  const uint4 *s1 = (const uint4 *)set->t1;
+  uint4 *d = (uint4 *)tab;
+  const uint32_t n1 = img.n_tabs * kJbT1Entries * 2u / 16u;
+  for (uint32_t i = tid; i < n1; i += L) d[i] = s1[i];
+  const uint4 *s2 = (const uint4 *)set->t2;
+  constexpr uint32_t n2 = kJbT2Tables * kJbT2Entries * 2u / 16u;
+  for (uint32_t i = tid; i < n2; i += L) d[n1 + i] = s2[i];
+}
+
+// Segmented sums over chunks: (f, n, d) = "an interval started here or to the left (then n counts from the image's
+// first block, d from that interval's start)", blocks, DC sums.  a (+) b with a to the left of b.
+struct Seg {
+  uint32_t f, n, d0, d1, d2;
+};
+__device__ __forceinline__ Seg seg_combine(const Seg &a, const Seg &b) {
+  Seg r;
+  r.f = a.f | b.f;
+  r.n = b.f ? b.n : a.n + b.n;
+  r.d0 = b.f ? b.d0 : a.d0 + b.d0;
+  r.d1 = b.f ? b.d1 : a.d1 + b.d1;
+  r.d2 = b.f ? b.d2 : a.d2 + b.d2;
+  return r;
+}
+__device__ __forceinline__ Seg seg_shfl_up(const Seg &x, int off) {
+  Seg r;
+  r.f = __shfl_up(x.f, off);
+  r.n = __shfl_up(x.n, off);
+  r.d0 = __shfl_up(x.d0, off);
+  r.d1 = __shfl_up(x.d1, off);
+  r.d2 = __shfl_up(x.d2, off);
+  return r;
+}
+// inclusive scan over the 256 lanes of the workgroup (scratch: 4 x 5 words of LDS); *total = all 256
+__device__ __forceinline__ Seg seg_scan_wg(Seg x, uint32_t *scratch, uint32_t tid, Seg *total) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const Seg t = seg_shfl_up(x, off);
+    if (lane >= (uint32_t)off) x = seg_combine(t, x);
+  }
+  __syncthreads();  // (the scratch may still be read from an earlier use)
+  if (lane == 63u) {
+    uint32_t *s = scratch + wave * 5u;
+    s[0] = x.f, s[1] = x.n, s[2] = x.d0, s[3] = x.d1, s[4] = x.d2;
+  }
+  __syncthreads();
+  Seg run{0, 0, 0, 0, 0};
+  Seg all{0, 0, 0, 0, 0};
+#pragma unroll
+  for (uint32_t w = 0; w < L / 64u; w++) {
+    const uint32_t *s = scratch + w * 5u;
+    const Seg t{s[0], s[1], s[2], s[3], s[4]};
+    if (w < wave) run = seg_combine(run, t);
+    all = seg_combine(all, t);
+  }
+  *total = all;
+  return seg_combine(run, x);
 }
 
 }  // namespace
 
-// one synchronisation pass (round 0: from the chunk starts; later rounds: from the left neighbour's exit state)
-__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuffLaunch p, const int round, const JbChunkState *src, JbChunkState *dst) {
-  __shared__ __attribute__((aligned(16))) LdsTables lds;
-  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
-  __shared__ uint8_t zz[64];
-  const int tid = threadIdx.x;
+// ---- synchronisation ----------------------------------------------------------------------------
+template <uint32_t kMaxChunk>
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuffLaunch p, const int launch) {
+  using Ly = Lay<kMaxChunk>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint32_t *const stream = (uint32_t *)(lds + Ly::off_stream);
+  uint32_t *const cpst = (uint32_t *)(lds + Ly::off_cp);
+  uint32_t *const xbit = (uint32_t *)(lds + Ly::off_xbit);
+  uint32_t *const xmeta = (uint32_t *)(lds + Ly::off_xmeta);
+  uint32_t *const misc = (uint32_t *)(lds + Ly::off_misc);
+  uint16_t *const tab = (uint16_t *)(lds + Ly::off_tab);
+  const uint32_t tid = threadIdx.x;
   const JbHuffWg wg = p.sync_wgs[blockIdx.x];
   const JbHuffImage img = p.images[wg.image];
-  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
-                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
-  const uint32_t ci = wg.first_interval + (uint32_t)tid;  // this lane's chunk
+  const uint32_t ci = wg.first_chunk + tid;
   const bool active = ci < img.n_chunks;
-  const uint32_t nb = img.ny + 2;
-  uint32_t bit = 0, end_bit = 0, nominal_start = 0;
-  ChunkLane st{0, 0, 0};
-  uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
-  bool skip = false;  // the start state is the one this chunk was decoded from last time: same results
-  if (active) {
-    const ChunkExtent x = chunk_extent(p, img, ci);
-    end_bit = x.end_bit;
-    nominal_start = x.start_bit;
-    JbChunkState in{x.start_bit, 0};
-    if (!x.first && round > 0) {
-      const JbChunkState prev = src[img.state_off + ci - 1];
-      in.bitpos = prev.bitpos;
-      in.meta = prev.meta & 0xffffu;  // k and the block's place in the MCU
+  const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);  // (idle lanes: valid addresses, nothing stored)
+  const ChunkGeo g = chunk_geo(p, img, gidx);
+  const uint32_t u0 = jbh_u_of_bit(g.start, g.start * 8u), u_end = u0 + (g.end - g.start) * 8u;
+  const size_t n_all = p.n_chunks_total;
+
+  JbChunkState entry{g.start * 8u, 0u}, exitst{0u, 0u};
+  uint32_t sum0 = 0, sum1 = 0, sum2 = 0;
+  bool changed = active;
+  if (launch > 0) {
+    // nothing but a new state at the workgroup's first chunk can change anything in this launch
+    bool c0 = false;
+    JbChunkState ne{0u, 0u};
+    if (tid == 0 && !g.first) {
+      ne = p.exit[gidx - 1u];
+      const JbChunkState en = p.entry[gidx];
+      c0 = ne.bitpos != en.bitpos || ((ne.meta ^ en.meta) & 0xffffu) != 0;
     }
-    if (round > 0) {
-      const JbChunkState last = p.state_in[img.state_off + ci];
-      skip = last.bitpos == in.bitpos && last.meta == in.meta;
-    }
-    if (skip) dst[img.state_off + ci] = src[img.state_off + ci];  // (this chunk's exit state of the pass before)
-    else p.state_in[img.state_off + ci] = in;
-    bit = in.bitpos;
-    st.k = in.meta & 0xffu;
-    st.blk = (in.meta >> 8) & 0xffu;
-    if (st.k > 63) st.k = 0;
-    if (st.blk >= nb) st.blk = 0;
+    if (!__syncthreads_or(c0)) return;
+    entry = p.entry[gidx];
+    exitst = p.exit[gidx];
+    const uint4 s = *(const uint4 *)(p.dcsum + 4u * (size_t)gidx);
+    sum0 = s.x, sum1 = s.y, sum2 = s.z;
+    changed = c0;
+    if (c0) entry = JbChunkState{ne.bitpos, ne.meta & 0xffffu};
   }
-  // a workgroup whose chunks are all in step has nothing to decode: the passes after convergence
-  // cost a launch and these few loads, not 18 KiB of tables per workgroup
-  if (!__syncthreads_or(active && !skip)) return;
-  {
-    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
-    uint4 *dst4 = (uint4 *)&lds.t;
-    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
-    if (tid < 64) zz[tid] = kZigZagDev[tid];
-  }
-  __syncthreads();
-  if (bit > end_bit) bit = end_bit;
-  Stream s;
-  s.base = p.scan + img.scan_off;
-  s.limit = (img.scan_len + 48u) & ~15u;
-  s.ring = rings + tid * kRing;
-  open_at_bit(s, (active && !skip) ? bit : 0u);
-  bool live = active && !skip && bit < end_bit;
-  // checkpoints: the first symbol boundary at or behind every kJbCheckpointBits bits of the chunk.  Pass 0
-  // records the state and the counts there; a later pass that arrives at a checkpoint in the state
-  // recorded for it has met the path of the chunk's previous decode and stops: what follows is known.
-  JbCheckpoint *const cps = p.cps + (size_t)(img.state_off + (active ? ci : 0u)) * 8u;
-  const uint32_t n_cp = img.chunk_bytes * 8u / kJbCheckpointBits - 1u;  // checkpoints inside a chunk of this image
-  uint32_t cp_i = 0, next_b = nominal_start + kJbCheckpointBits;
-  while (next_b <= bit && cp_i < n_cp) {  // a start behind the chunk's first checkpoints (a lane far out of step):
-    if (live) ((uint4 *)(cps + cp_i))[0] = make_uint4(0xffffffffu, 0u, 0u, 0u);  // what they hold is no longer on this chunk's path
-    cp_i++;
-    next_b += kJbCheckpointBits;
-  }
-  bool met = false;
-  uint32_t met_at = 0;
-  for (;;) {
-    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-    if (live) s.top_up();
+  load_tables(tab, p, img, tid);
+  if (tid < 16) ((uint32_t *)misc)[tid] = ((const uint32_t *)kZz2Dev)[tid];
+  if (active) load_stream<Ly::kRows>(stream, p.scan + img.scan_off, g.start, tid);
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-    if (live) {
-      if (!chunk_step<false>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, nullptr)) {
-        // not a possible continuation of this state: the lane is out of step (or the data is corrupt,
-        // which the write pass will report) -- move on by one bit and expect a block to start; and
-        // since a wrong guess of the block's place in the MCU (luma tables on a chroma block) is what
-        // produces most impossible symbols and does not correct itself, try the next place: one
-        // synchronisation pass fewer on 4:4:4 and on 4:2:0 files, +8 % on 4:2:0 batches
-        s.consume(1);
-        st.k = 0;
-        if (++st.blk >= nb) st.blk = 0;  // (jumping between the luma and the chroma places instead: no better)
+  for (uint32_t i = 0; i < Ly::kNcp; i++)
+    cpst[i * L + tid] = launch > 0 ? (p.cps[i * n_all + gidx].state & 0xfffffu) : 0xffffffffu;
+  __syncthreads();
+
+  JbhCtx cx;
+  cx.scol = stream + tid;
+  cx.tab = tab;
+  cx.zz2 = (const uint8_t *)misc;
+  cx.lut_ac = img.lut_ac, cx.lut_dc = img.lut_dc, cx.lut_comp = img.lut_comp;
+  cx.nb4 = img.nb * 4u;
+  cx.blk_bytes = img.blk_bytes;
+
+  for (int pass = 0; pass < kMaxPasses; pass++) {
+    // (wave-uniform entry: a wave none of whose lanes changed goes straight to the barrier)
+    if (__builtin_amdgcn_ballot_w64(changed) != 0) {
+      JbhLane st;
+      {
+        const uint32_t bit = entry.bitpos < g.start * 8u ? g.start * 8u : entry.bitpos;
+        const uint32_t u = jbh_u_of_bit(g.start, bit);
+        st.u = u < u_end ? u : u_end;
+        st.k = entry.meta & 0xffu;
+        st.blk4 = ((entry.meta >> 8) & 0xffu) * 4u;
+        if (st.k > 63u) st.k = 0;
+        if (st.blk4 >= cx.nb4) st.blk4 = 0;
+        st.nblk = 0;
       }
-      const uint32_t bp = (uint32_t)s.bitpos();
-      live = bp < end_bit;
-      if (bp >= next_b && cp_i < n_cp) {  // rare: at most n_cp times per chunk
-        const uint32_t meta = st.k | (st.blk << 8);
-        uint4 *rec = (uint4 *)(cps + cp_i);
-        if (round > 0 && live) {
-          const uint4 old = rec[0];
-          if (old.x == bp && old.y == meta) {
-            met = true;
-            met_at = cp_i;
-            live = false;
+      uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
+      bool live = changed && st.u < u_end;
+      bool met = false;
+      uint32_t met_i = 0;
+      while (live) {
+        const uint32_t up = st.u;
+        (void)jbh_step<false>(cx, st, dc0, dc1, dc2, nullptr, 0u);
+        live = st.u < u_end;
+        if (((st.u ^ up) >> 8) != 0) {  // a checkpoint: the first symbol boundary behind a multiple of 256 bits
+          const uint32_t i = (st.u >> 8) - 1u;
+          if (i < Ly::kNcp) {
+            const uint32_t s = jbh_pack_state(st);
+            if (live && cpst[i * L + tid] == s) {
+              met = true;  // the path of this chunk's previous decode: what follows is known
+              met_i = i;
+              live = false;
+            } else {
+              cpst[i * L + tid] = s;
+              *(uint4 *)(p.cps + i * n_all + gidx) = make_uint4(s | (st.nblk << 20), dc0, dc1, dc2);
+            }
           }
         }
-        if (!met) {
-          rec[0] = make_uint4(bp, meta, st.nblk, dc0);
-          rec[1] = make_uint4(dc1, dc2, 0u, 0u);
-        }
-        cp_i++;
-        next_b += kJbCheckpointBits;
       }
-    }
-  }
-  if (active && !skip) {
-    if (met) {
-      // the rest of the chunk is what the previous decode of this chunk found: its exit state, and its
-      // counts shifted by the difference of the counts at the meeting place; the later checkpoints
-      // (recorded relative to the old counts) move by the same amounts
-      const JbChunkState old_exit = src[img.state_off + ci];
-      const uint4 old_sum = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
-      const uint4 a = ((const uint4 *)(cps + met_at))[0], b = ((const uint4 *)(cps + met_at))[1];
-      const uint32_t d_n = st.nblk - a.z, d0 = dc0 - a.w, d1 = dc1 - b.x, d2 = dc2 - b.y;
-      for (uint32_t i = met_at; i < n_cp; i++) {
-        uint4 *rec = (uint4 *)(cps + i);
-        const uint4 r0 = rec[0], r1 = rec[1];
-        rec[0] = make_uint4(r0.x, r0.y, r0.z + d_n, r0.w + d0);
-        rec[1] = make_uint4(r1.x + d1, r1.y + d2, 0u, 0u);
-      }
-      dst[img.state_off + ci] = JbChunkState{old_exit.bitpos, (old_exit.meta & 0xffffu) | ((((old_exit.meta >> 16) + d_n) & 0xffffu) << 16)};
-      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(old_sum.x + d0, old_sum.y + d1, old_sum.z + d2, 0u);
-    } else {
-      dst[img.state_off + ci] = JbChunkState{(uint32_t)s.bitpos(), st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)};
-      *(uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci)) = make_uint4(dc0, dc1, dc2, 0u);
-    }
-  }
-}
-
-// exclusive prefix sums over the chunks of each interval -- blocks completed, DC differences per
-// component -- restarting at every interval's first chunk: one workgroup per image
-__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_scan_kernel(const JbHuffLaunch p, const JbChunkState *fin) {
-  __shared__ uint4 part[kJbHuffLanes];
-  __shared__ uint32_t restarted[kJbHuffLanes];
-  const JbHuffImage img = p.images[p.sync_images[blockIdx.x]];
-  const uint32_t n = img.n_chunks, per = (n + kJbHuffLanes - 1) / kJbHuffLanes;
-  const uint32_t lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
-  const uint32_t blocks_per_interval = img.ri * (img.ny + 2);
-  const uint4 *sums = (const uint4 *)p.dcsum;
-  uint4 acc = make_uint4(0, 0, 0, 0);
-  uint32_t any = 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t sg = p.chunks[img.state_off + i].seg;
-    if (sg >> 31) {
-      acc = make_uint4((sg & 0x7fffffffu) * blocks_per_interval, 0, 0, 0);
-      any = 1;
-    }
-    const uint4 d = sums[img.state_off + i];
-    acc.x += fin[img.state_off + i].meta >> 16;
-    acc.y += d.x;
-    acc.z += d.y;
-    acc.w += d.z;
-  }
-  part[threadIdx.x] = acc;
-  restarted[threadIdx.x] = any;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint4 run = make_uint4(0, 0, 0, 0);
-    for (int i = 0; i < kJbHuffLanes; i++) {
-      const uint4 v = part[i];
-      part[i] = run;
-      if (restarted[i]) run = v;  // (v is absolute from the last interval start in lane i's range on)
-      else run = make_uint4(run.x + v.x, run.y + v.y, run.z + v.z, run.w + v.w);
-    }
-  }
-  __syncthreads();
-  acc = part[threadIdx.x];
-  uint4 *base = (uint4 *)p.base;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t sg = p.chunks[img.state_off + i].seg;
-    if (sg >> 31) acc = make_uint4((sg & 0x7fffffffu) * blocks_per_interval, 0, 0, 0);
-    base[img.state_off + i] = acc;
-    const uint4 d = sums[img.state_off + i];
-    acc.x += fin[img.state_off + i].meta >> 16;
-    acc.y += d.x;
-    acc.z += d.y;
-    acc.w += d.z;
-  }
-}
-
-// the writing pass: decode from the left neighbour's final exit state, store, verify
-__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuffLaunch p, const JbChunkState *fin) {
-  __shared__ __attribute__((aligned(16))) LdsTables lds;
-  __shared__ __attribute__((aligned(16))) uint8_t rings[kJbHuffLanes * kRing];
-  __shared__ uint8_t zz[64];
-  const int tid = threadIdx.x;
-  const JbHuffWg wg = p.sync_wgs[blockIdx.x];
-  const JbHuffImage img = p.images[wg.image];
-  const uint32_t slots = (uint32_t)img.dc_slot[0] | ((uint32_t)img.dc_slot[1] << 1) | ((uint32_t)img.dc_slot[2] << 2) |
-                         ((uint32_t)img.ac_slot[0] << 4) | ((uint32_t)img.ac_slot[1] << 5) | ((uint32_t)img.ac_slot[2] << 6);
-  {
-    const uint4 *src4 = (const uint4 *)(p.tables + img.table_set);
-    uint4 *dst4 = (uint4 *)&lds.t;
-    for (int i = tid; i < (int)(sizeof(JbHuffTables) / 16); i += kJbHuffLanes) dst4[i] = src4[i];
-    if (tid < 64) zz[tid] = kZigZagDev[tid];
-  }
-  __syncthreads();
-  const uint32_t ci = wg.first_interval + (uint32_t)tid;
-  const bool active = ci < img.n_chunks;
-  const uint32_t nb = img.ny + 2;
-  uint32_t bit = 0, end_bit = 0, block = 0, block_end = 0, base0 = 0, base1 = 0, base2 = 0;
-  bool last = false;
-  ChunkLane st{0, 0, 0};
-  uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
-  JbChunkState want{0, 0};
-  if (active) {
-    const ChunkExtent x = chunk_extent(p, img, ci);
-    end_bit = x.end_bit;
-    last = x.last;
-    bit = x.start_bit;
-    want = fin[img.state_off + ci];
-    const uint4 b = ((const uint4 *)p.base)[img.state_off + ci];
-    block = b.x;
-    dc0 = base0 = b.y;
-    dc1 = base1 = b.z;
-    dc2 = base2 = b.w;
-    // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
-    const uint32_t m1 = (x.seg + 1) * img.ri < img.n_mcus ? (x.seg + 1) * img.ri : img.n_mcus;
-    block_end = m1 * nb;
-    if (!x.first) {
-      const JbChunkState prev = fin[img.state_off + ci - 1];
-      bit = prev.bitpos;
-      st.k = prev.meta & 0xffu;
-      st.blk = (prev.meta >> 8) & 0xffu;
-      if (st.k > 63) st.k = 0;
-      if (st.blk >= nb) st.blk = 0;
-    }
-  }
-  const bool overran = active && bit > end_bit;  // the chunk before consumed bits beyond this one's (= the interval's) end
-  if (bit > end_bit) bit = end_bit;
-  if (block_end > img.n_blocks) block_end = img.n_blocks;  // (the output is sized for n_blocks)
-  Stream s;
-  s.base = p.scan + img.scan_off;
-  s.limit = (img.scan_len + 48u) & ~15u;
-  s.ring = rings + tid * kRing;
-  open_at_bit(s, active ? bit : 0u);
-  int16_t *const coef = (int16_t *)((uint8_t *)p.coef + img.coef_off);
-  uint32_t err = 0;
-  bool live = active && bit < end_bit && block < block_end;
-  // (four steps per top-up, written as an unrolled inner loop: with the step counter tested in the
-  // loop body the compiler copied a dozen loop-carried registers back and forth in every iteration)
-  for (;;) {
-    if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-    if (live) s.top_up();
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (live) {
-        if (!chunk_step<true>(s, lds.t, zz, slots, img.ny, nb, st, dc0, dc1, dc2, coef + (int64_t)(block + st.nblk) * 64)) {
-          err |= 1;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2 below)
-          live = false;
+      if (changed) {
+        if (met) {
+          // the rest of the chunk is what the previous decode found: its exit state, its counts shifted by the
+          // difference of the counts at the meeting place; the later checkpoints move by the same amounts
+          const uint4 old = *(const uint4 *)(p.cps + met_i * n_all + gidx);
+          const uint32_t dn = st.nblk - (old.x >> 20), d0 = dc0 - old.y, d1 = dc1 - old.z, d2 = dc2 - old.w;
+          for (uint32_t i = met_i; i < Ly::kNcp; i++) {
+            uint4 *rec = (uint4 *)(p.cps + i * n_all + gidx);
+            const uint4 r = *rec;
+            *rec = make_uint4(r.x + (dn << 20), r.y + d0, r.z + d1, r.w + d2);
+          }
+          exitst.meta = (exitst.meta & 0xffffu) | ((((exitst.meta >> 16) + dn) & 0xffffu) << 16);
+          sum0 += d0, sum1 += d1, sum2 += d2;
         } else {
-          live = (uint32_t)s.bitpos() < end_bit && block + st.nblk < block_end;
+          exitst.bitpos = jbh_bit_of_u(g.start, st.u);
+          exitst.meta = st.k | ((st.blk4 >> 2) << 8) | ((st.nblk & 0xffffu) << 16);
+          sum0 = dc0, sum1 = dc1, sum2 = dc2;
         }
       }
     }
+    xbit[tid] = exitst.bitpos;
+    xmeta[tid] = exitst.meta & 0xffffu;
+    __syncthreads();
+    changed = false;
+    if (active && !g.first && tid > 0) {
+      const uint32_t nbit = xbit[tid - 1u], nmeta = xmeta[tid - 1u];
+      if (nbit != entry.bitpos || nmeta != (entry.meta & 0xffffu)) {
+        entry = JbChunkState{nbit, nmeta};
+        changed = true;
+      }
+    }
+    if (!__syncthreads_or(changed)) break;
   }
   if (active) {
-    if (last) {
+    p.entry[gidx] = entry;
+    p.exit[gidx] = exitst;
+    *(uint4 *)(p.dcsum + 4u * (size_t)gidx) = make_uint4(sum0, sum1, sum2, 0u);
+  }
+  // what the workgroup's chunks add up to, for the writing pass
+  Seg mine{0, 0, 0, 0, 0};
+  if (active) {
+    mine.f = g.first ? 1u : 0u;
+    mine.n = (exitst.meta >> 16) + (g.first ? g.seg * img.ri * img.nb : 0u);
+    mine.d0 = sum0, mine.d1 = sum1, mine.d2 = sum2;
+  }
+  Seg total;
+  (void)seg_scan_wg(mine, misc + 16, tid, &total);
+  if (tid == 0) {
+    JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / L;
+    o->has_first = total.f;
+    o->blocks = total.n;
+    o->dc[0] = total.d0, o->dc[1] = total.d1, o->dc[2] = total.d2;
+  }
+}
+
+// ---- the writing pass: decode from the left neighbour's final exit state, store, verify ----------------
+template <uint32_t kMaxChunk>
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuffLaunch p) {
+  using Ly = Lay<kMaxChunk>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint32_t *const stream = (uint32_t *)(lds + Ly::off_stream);
+  uint32_t *const misc = (uint32_t *)(lds + Ly::off_misc);
+  uint16_t *const tab = (uint16_t *)(lds + Ly::off_tab);
+  const uint32_t tid = threadIdx.x;
+  const JbHuffWg wg = p.wgs[blockIdx.x];
+  const JbHuffImage img = p.images[wg.image];
+  const uint32_t ci = wg.first_chunk + tid;
+  const bool active = ci < img.n_chunks;
+  const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);
+  const ChunkGeo g = chunk_geo(p, img, gidx);
+  const uint32_t u0 = jbh_u_of_bit(g.start, g.start * 8u), u_end = u0 + (g.end - g.start) * 8u;
+  const uint32_t bpi = img.ri * img.nb;  // blocks per restart interval
+
+  load_tables(tab, p, img, tid);
+  if (tid < 16) ((uint32_t *)misc)[tid] = ((const uint32_t *)kZz2Dev)[tid];
+  if (active) load_stream<Ly::kRows>(stream, p.scan + img.scan_off, g.start, tid);
+
+  // where the chunk starts: the block, and the DC predictors there
+  uint32_t err = 0;
+  JbChunkState entry{g.start * 8u, 0u}, want{0u, 0u};
+  uint32_t block = g.seg * bpi, base0 = 0, base1 = 0, base2 = 0, want0 = 0, want1 = 0, want2 = 0;
+  if (img.needs_sync) {
+    Seg mine{0, 0, 0, 0, 0};
+    if (active) {
+      want = p.exit[gidx];
+      const uint4 s = *(const uint4 *)(p.dcsum + 4u * (size_t)gidx);
+      want0 = s.x, want1 = s.y, want2 = s.z;
+      mine.f = g.first ? 1u : 0u;
+      mine.n = (want.meta >> 16) + (g.first ? g.seg * bpi : 0u);
+      mine.d0 = s.x, mine.d1 = s.y, mine.d2 = s.z;
+      if (!g.first) {
+        // the state this chunk starts from: its left neighbour's final exit state -- which must be the state the
+        // synchronisation decoded this chunk from, or the chunks are not in step
+        const JbChunkState prev = p.exit[gidx - 1u];
+        const JbChunkState en = p.entry[gidx];
+        entry = JbChunkState{prev.bitpos, prev.meta & 0xffffu};
+        if (en.bitpos != prev.bitpos || ((en.meta ^ prev.meta) & 0xffffu) != 0) err |= 4u;
+      }
+    }
+    // the workgroups of this image to the left, folded in order: the last one that holds an interval start counts
+    // from the image's first block, the ones behind it add up
+    const uint32_t w_first = img.wg0, w_me = img.wg0 + wg.first_chunk / L;
+    uint32_t *red = misc + 40;  // [0] index + 1 of the last workgroup with an interval start, [1..4] sums
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    uint32_t last_f = 0;
+    for (uint32_t w = w_first + tid; w < w_me; w += L)
+      if (p.wgsum[w].has_first) last_f = w - w_first + 1u;
+    if (last_f) atomicMax(&red[0], last_f);
+    __syncthreads();
+    const uint32_t from = red[0];  // (0: none of them; the image's first chunk starts an interval, so then w_me == w_first ... or the sums below are complete)
+    uint32_t a_n = 0, a0 = 0, a1 = 0, a2 = 0;
+    for (uint32_t w = w_first + tid; w < w_me; w += L) {
+      if (w - w_first + 1u >= from) {
+        const JbWgSum s = p.wgsum[w];
+        a_n += s.blocks, a0 += s.dc[0], a1 += s.dc[1], a2 += s.dc[2];
+      }
+    }
+    if (a_n) atomicAdd(&red[1], a_n);
+    if (a0) atomicAdd(&red[2], a0);
+    if (a1) atomicAdd(&red[3], a1);
+    if (a2) atomicAdd(&red[4], a2);
+    __syncthreads();
+    const Seg carry{from ? 1u : 0u, red[1], red[2], red[3], red[4]};
+    Seg total;
+    const Seg incl = seg_scan_wg(mine, misc + 16, tid, &total);
+    // exclusive: what lies to the left of this lane
+    Seg left = seg_shfl_up(incl, 1);
+    if ((tid & 63u) == 0) {
+      // (the wave's first lane: the waves to the left, as seg_scan_wg left them in the scratch)
+      left = Seg{0, 0, 0, 0, 0};
+      for (uint32_t w = 0; w < (tid >> 6); w++) {
+        const uint32_t *s = misc + 16 + w * 5u;
+        left = seg_combine(left, Seg{s[0], s[1], s[2], s[3], s[4]});
+      }
+    }
+    left = seg_combine(carry, left);
+    if (!g.first) block = left.n, base0 = left.d0, base1 = left.d1, base2 = left.d2;
+  }
+  __syncthreads();
+
+  JbhCtx cx;
+  cx.scol = stream + tid;
+  cx.tab = tab;
+  cx.zz2 = (const uint8_t *)misc;
+  cx.lut_ac = img.lut_ac, cx.lut_dc = img.lut_dc, cx.lut_comp = img.lut_comp;
+  cx.nb4 = img.nb * 4u;
+  cx.blk_bytes = img.blk_bytes;
+
+  // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
+  uint32_t block_end = (g.seg + 1u) * img.ri < img.n_mcus ? (g.seg + 1u) * bpi : img.n_mcus * img.nb;
+  if (block_end > img.n_blocks) block_end = img.n_blocks;  // (the output is sized for n_blocks)
+  JbhLane st;
+  const bool overran = active && entry.bitpos > g.end * 8u;  // the chunk before consumed bits beyond this one's (= the interval's) end
+  {
+    const uint32_t bit = entry.bitpos < g.start * 8u ? g.start * 8u : entry.bitpos;
+    const uint32_t u = jbh_u_of_bit(g.start, bit);
+    st.u = u < u_end ? u : u_end;
+    st.k = entry.meta & 0xffu;
+    st.blk4 = ((entry.meta >> 8) & 0xffu) * 4u;
+    if (st.k > 63u) st.k = 0;
+    if (st.blk4 >= cx.nb4) st.blk4 = 0;
+    st.nblk = 0;
+  }
+  uint32_t dc0 = base0, dc1 = base1, dc2 = base2;
+  uint8_t *const coef = (uint8_t *)p.coef + img.coef_off;
+  bool live = active && st.u < u_end && block < block_end;
+  while (live) {
+    if (jbh_step<true>(cx, st, dc0, dc1, dc2, coef, block)) {
+      err |= 1u;  // reference jpeg.cpp:372-385: the stream is corrupt (or the chunks are not in step: bit 2)
+      live = false;
+    } else {
+      live = st.u < u_end && block + st.nblk < block_end;
+    }
+  }
+  if (active) {
+    if (g.last) {
       // the interval's data ends before its blocks do, or its last symbol reaches beyond its last byte
       // (the host decoder's "entropy-coded data ends early": jb_frontend.cpp decode_interval)
-      if (block + st.nblk != block_end || st.k != 0 || (uint32_t)s.bitpos() > end_bit || overran) err |= 2;
-    } else {
-      // this chunk must end where the synchronisation passes said it would, after as many blocks, and with
-      // the DC differences adding up to what they recorded (the predictors of the chunks behind it rest on those)
-      const uint4 sums = *(const uint4 *)(p.dcsum + 4 * (size_t)(img.state_off + ci));
-      if ((uint32_t)s.bitpos() != want.bitpos || (st.k | (st.blk << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta ||
-          dc0 - base0 != sums.x || dc1 - base1 != sums.y || dc2 - base2 != sums.z)
-        err |= 4;
+      if (block + st.nblk != block_end || st.k != 0 || st.u > u_end || overran) err |= 2u;
+    } else if (img.needs_sync) {
+      // this chunk must end where the synchronisation passes said it would, after as many blocks, and with the DC
+      // differences adding up to what they recorded (the predictors of the chunks behind it rest on those)
+      if (jbh_bit_of_u(g.start, st.u) != want.bitpos || (st.k | ((st.blk4 >> 2) << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta ||
+          dc0 - base0 != want0 || dc1 - base1 != want1 || dc2 - base2 != want2)
+        err |= 4u;
     }
     if (err) atomicOr(p.status + wg.image, err);
   }
@@ -681,11 +464,11 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
 
 // A small packed submission (one image) is fetched from the pinned host blob by a kernel instead of a
 // copy-engine transfer: the decoding kernels behind it on the stream then start without the ~100 us
-// a compute queue waits for the copy engine's completion (one 1080p decode(bytes): 1.2 ms in all).
+// a compute queue waits for the copy engine's completion.
 __global__ __launch_bounds__(256) void jb_huff_fetch_kernel(uint4 *dst, const uint4 *src, uint32_t n16) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
 }
-// the coefficient area and the status words are zeroed by a kernel of this library as well (the decoders store
+// the coefficient area and the status words are zeroed by a kernel of this library as well (the decoder stores
 // non-zero coefficients only)
 __global__ __launch_bounds__(256) void jb_huff_zero_kernel(uint4 *dst, uint64_t n16) {
   const uint4 z = make_uint4(0, 0, 0, 0);
@@ -710,22 +493,20 @@ hipError_t jbk_huff_fetch(void *d_dst, const void *h_pinned_src, size_t bytes, h
 
 hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
   (void)hipGetLastError();
-  if (p.n_wgs > 0) hipLaunchKernelGGL(jb_huff_kernel, dim3((unsigned)p.n_wgs), dim3(kJbHuffLanes), 0, stream, p);
-  if (p.n_sync_wgs > 0 && p.n_sync_images > 0) {
-    const dim3 grid((unsigned)p.n_sync_wgs), block(kJbHuffLanes);
-    // JPEGBLK_HUFF_EXTRA_LDS=N (experiment): N bytes of unused dynamic LDS per workgroup of the decoding
-    // kernels -- fewer workgroups per CU; how much the chunk decoder depends on occupancy
-    static const unsigned extra_lds = getenv("JPEGBLK_HUFF_EXTRA_LDS") ? (unsigned)atoi(getenv("JPEGBLK_HUFF_EXTRA_LDS")) : 0u;
-    const JbChunkState *fin = nullptr;
-    const int rounds = p.sync_rounds > 0 ? p.sync_rounds : kJbSyncRounds;
-    for (int r = 0; r < rounds; r++) {
-      const JbChunkState *src = (r & 1) ? p.state_a : p.state_b;
-      JbChunkState *dst = (r & 1) ? p.state_b : p.state_a;
-      hipLaunchKernelGGL(jb_huff_sync_kernel, grid, block, extra_lds, stream, p, r, src, dst);
-      fin = dst;
+  const dim3 block(kJbHuffLanes);
+  const uint32_t n_tabs = p.max_tabs < 2u ? 2u : p.max_tabs > kJbMaxTabs ? kJbMaxTabs : p.max_tabs;
+  const bool small = p.max_chunk_bytes <= 64u;
+  const unsigned lds = small ? Lay<64>::bytes(n_tabs) : Lay<128>::bytes(n_tabs);
+  if (p.n_sync_wgs > 0) {
+    const int launches = p.sync_launches > 0 ? p.sync_launches : kJbSyncLaunches;
+    for (int l = 0; l < launches; l++) {
+      if (small) hipLaunchKernelGGL(jb_huff_sync_kernel<64>, dim3((unsigned)p.n_sync_wgs), block, lds, stream, p, l);
+      else hipLaunchKernelGGL(jb_huff_sync_kernel<128>, dim3((unsigned)p.n_sync_wgs), block, lds, stream, p, l);
     }
-    hipLaunchKernelGGL(jb_huff_scan_kernel, dim3((unsigned)p.n_sync_images), block, 0, stream, p, fin);
-    hipLaunchKernelGGL(jb_huff_write_kernel, grid, block, extra_lds, stream, p, fin);
+  }
+  if (p.n_wgs > 0) {
+    if (small) hipLaunchKernelGGL(jb_huff_write_kernel<64>, dim3((unsigned)p.n_wgs), block, lds, stream, p);
+    else hipLaunchKernelGGL(jb_huff_write_kernel<128>, dim3((unsigned)p.n_wgs), block, lds, stream, p);
   }
   return hipGetLastError();
 }
