@@ -590,8 +590,8 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   p.chunks = (const JbChunkDesc *)(d + lay.off_chunks);
   p.entry = (JbChunkState *)(dw + lay.off_entry);
   p.exit = (JbChunkState *)(dw + lay.off_exit);
-  p.cps = (JbCheckpoint *)(dw + lay.off_cps);
-  p.dcsum = (uint32_t *)(dw + lay.off_dcsum);
+  p.cps = (uint32_t *)(dw + lay.off_cps);
+  p.chunk_dc = (JbChunkDc *)(dw + lay.off_chunk_dc);
   p.wgsum = (JbWgSum *)(dw + lay.off_wgsum);
   p.n_chunks_total = lay.n_chunks;
   // (one workgroup per image: its first chunk starts an interval, nothing to hand over between launches)
@@ -1070,8 +1070,8 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
   lay->off_entry = a16(lay->total);
   lay->off_exit = a16(lay->off_entry + n_chunks * sizeof(JbChunkState));
   lay->off_cps = a16(lay->off_exit + n_chunks * sizeof(JbChunkState));
-  lay->off_dcsum = a16(lay->off_cps + n_chunks * kJbCheckpoints * sizeof(JbCheckpoint));
-  lay->off_wgsum = (a16(lay->off_dcsum + n_chunks * 16) + 31) & ~(size_t)31;
+  lay->off_chunk_dc = (a16(lay->off_cps + n_chunks * kJbCheckpoints * 4) + 31) & ~(size_t)31;
+  lay->off_wgsum = lay->off_chunk_dc + n_chunks * sizeof(JbChunkDc);
   lay->device_total = a16(lay->off_wgsum + n_wg * sizeof(JbWgSum));
   lay->n = n;
   lay->n_wg = (int)n_wg;

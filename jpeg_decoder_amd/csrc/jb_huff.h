@@ -16,8 +16,8 @@
 //                 run + 1, and the step takes 1 off again | EOB 82
 //               so "k + adv in 65..81" is exactly the reference's "Invalid AC length" (jpeg.cpp:372).
 // First level: the first kJbT1Bits bits of the window.  A code longer than that (all of them sit at
-// the top of the code space) has total == 0 and a non-zero entry: 2 * entry is where its
-// second-level table of 2^(16 - kJbT1Bits) entries, indexed by the following bits, starts in LDS.  Symbols the
+// the top of the code space) has an entry of 1..kJbT2Tables: the number + 1 of its second-level table
+// of 2^(16 - kJbT1Bits) entries, indexed by the following bits (no symbol's entry is below 512).  Symbols the
 // reference rejects (DC size > 11, AC size > 10) are not in the tables at all: entry 0.
 // Up to three tables per kind (a frame has three components): the AC tables in use first, then the
 // DC tables in use (JbHuffImage::n_tabs first-level tables in all); in LDS the second-level pool
@@ -26,7 +26,6 @@ constexpr int kJbT1Bits = 10;
 constexpr int kJbT2Bits = 16 - kJbT1Bits;
 constexpr uint32_t kJbT1Entries = 1u << kJbT1Bits;
 constexpr uint32_t kJbT2Entries = 1u << kJbT2Bits;
-static_assert(kJbT2Entries >= 64, "a first-level entry names a second-level table by (index of its first entry) / 2 with five zero bits below");
 constexpr uint32_t kJbT2Tables = 24;  // second-level tables a set can hold (Annex K needs 11)
 constexpr uint32_t kJbMaxTabs = 6;    // first-level tables: up to three AC and three DC
 struct JbHuffTables {
@@ -92,19 +91,24 @@ struct JbChunkState {
 // at the first symbol boundary behind every kJbCheckpointBits bits (counted in the lane's local
 // coordinates, see jb_huff_core.h), with the counts up to there.
 constexpr uint32_t kJbCheckpointBits = 256;
-constexpr uint32_t kJbCheckpoints = 4;  // records per chunk (a 128-byte chunk crosses at most four boundaries)
-struct JbCheckpoint {   // 16 bytes, stored [checkpoint][chunk]
-  uint32_t state;       // local position u | k << 11 | block-in-MCU << 17 | blocks completed before this place << 20
-  uint32_t dc[3];       // DC differences summed before this place, per component
-};
+constexpr uint32_t kJbCheckpoints = 4;  // records per chunk (a 128-byte chunk crosses at most four boundaries), stored [checkpoint][chunk]:
+                                        // local position u | k << 11 | block-in-MCU << 17 | blocks completed before this place << 20 (jbh_pack_state)
 
 // What a workgroup's chunks add up to, for the writing pass's bases (segmented sums over the chunks
 // of each interval, restarting at every interval's first chunk)
 struct JbWgSum {
   uint32_t has_first;   // 1: a chunk of this workgroup is the first of its interval
   uint32_t blocks;      // has_first: index of the block behind the workgroup's last chunk, counted from the image's
-                        // first; else blocks completed by the workgroup's chunks
+                        // first; else blocks completed by the workgroup's chunks (written by the synchronisation)
   uint32_t dc[3];       // DC differences summed: behind the last interval start (has_first), else over all chunks
+                        // (written by the writing pass)
+  uint32_t pad[3];
+};
+// What the writing pass leaves for jb_huff_dc_kernel, per chunk
+struct JbChunkDc {
+  uint32_t dc[3];        // DC differences of the blocks whose DC symbol lies in the chunk, summed per component
+  uint32_t first_block;  // the first of those blocks ...
+  uint32_t count;        // ... and how many they are
   uint32_t pad[3];
 };
 
@@ -123,8 +127,8 @@ struct JbHuffLaunch {
   // device scratch, one entry per chunk each
   JbChunkState *entry;         // the state the chunk was last decoded from
   JbChunkState *exit;          // and the state that decode ended in
-  JbCheckpoint *cps;           // kJbCheckpoints records per chunk, [checkpoint][chunk]
-  uint32_t *dcsum;             // 4 words per chunk: sum of the DC differences decoded in the chunk, per component (Y, Cb, Cr, -)
+  uint32_t *cps;               // kJbCheckpoints records per chunk, [checkpoint][chunk] (kept between the synchronisation launches)
+  JbChunkDc *chunk_dc;         // what the writing pass leaves for jb_huff_dc_kernel
   JbWgSum *wgsum;              // one per workgroup (indexed like `wgs`)
   uint32_t n_chunks_total;     // chunks of the submission (the [checkpoint][chunk] arrays' row length)
   int32_t sync_launches;       // synchronisation launches (>= 1)
@@ -165,7 +169,7 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
 struct JbHuffLayout {
   size_t off_img = 0, off_wg = 0, off_sync_wg = 0, off_tab = 0, off_starts = 0, off_chunks = 0, off_scan = 0, total = 0;
   // device-only scratch behind the uploaded bytes
-  size_t off_entry = 0, off_exit = 0, off_cps = 0, off_dcsum = 0, off_wgsum = 0, device_total = 0;
+  size_t off_entry = 0, off_exit = 0, off_cps = 0, off_chunk_dc = 0, off_wgsum = 0, device_total = 0;
   int n = 0, n_wg = 0, n_sync_wg = 0;
   uint32_t n_chunks = 0, max_chunk_bytes = 0, max_tabs = 0;
   int64_t coef_stride = 0;

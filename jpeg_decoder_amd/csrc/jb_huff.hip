@@ -175,9 +175,52 @@ __device__ __forceinline__ Seg seg_scan_wg(Seg x, uint32_t *scratch, uint32_t ti
   return seg_combine(run, x);
 }
 
+// what the workgroups of this image to the left of workgroup w_me add up to, folded in order: the last one that
+// holds an interval start counts from the image's first block (its DC sums from that start), the ones behind it add
+// up.  `red`: 8 words of LDS.
+__device__ __forceinline__ Seg fold_left_workgroups(const JbHuffLaunch &p, uint32_t w_first, uint32_t w_me, uint32_t *red, uint32_t tid) {
+  if (tid < 8) red[tid] = 0;
+  __syncthreads();
+  uint32_t last_f = 0;
+  for (uint32_t w = w_first + tid; w < w_me; w += L)
+    if (p.wgsum[w].has_first) last_f = w - w_first + 1u;
+  if (last_f) atomicMax(&red[0], last_f);
+  __syncthreads();
+  const uint32_t from = red[0];  // (0 only when there is no workgroup to the left: an image's first chunk starts an interval)
+  uint32_t a_n = 0, a0 = 0, a1 = 0, a2 = 0;
+  for (uint32_t w = w_first + tid; w < w_me; w += L) {
+    if (w - w_first + 1u >= from) {
+      const JbWgSum s = p.wgsum[w];
+      a_n += s.blocks, a0 += s.dc[0], a1 += s.dc[1], a2 += s.dc[2];
+    }
+  }
+  if (a_n) atomicAdd(&red[1], a_n);
+  if (a0) atomicAdd(&red[2], a0);
+  if (a1) atomicAdd(&red[3], a1);
+  if (a2) atomicAdd(&red[4], a2);
+  __syncthreads();
+  return Seg{from ? 1u : 0u, red[1], red[2], red[3], red[4]};
+}
+// the exclusive scan of the workgroup's lanes behind `carry`: what lies to the left of this lane
+__device__ __forceinline__ Seg scan_left(const Seg &mine, const Seg &carry, uint32_t *scratch, uint32_t tid, Seg *total) {
+  const Seg incl = seg_scan_wg(mine, scratch, tid, total);
+  Seg left = seg_shfl_up(incl, 1);
+  if ((tid & 63u) == 0) {
+    // (the wave's first lane: the waves to the left, as seg_scan_wg left them in the scratch)
+    left = Seg{0, 0, 0, 0, 0};
+    for (uint32_t w = 0; w < (tid >> 6); w++) {
+      const uint32_t *s = scratch + w * 5u;
+      left = seg_combine(left, Seg{s[0], s[1], s[2], s[3], s[4]});
+    }
+  }
+  return seg_combine(carry, left);
+}
+
 }  // namespace
 
 // ---- synchronisation ----------------------------------------------------------------------------
+constexpr uint32_t kMet = 0x80000000u;  // a lane's position once it has met its previous path: kMet | checkpoint
+
 template <uint32_t kMaxChunk>
 __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuffLaunch p, const int launch) {
   using Ly = Lay<kMaxChunk>;
@@ -199,7 +242,6 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const size_t n_all = p.n_chunks_total;
 
   JbChunkState entry{g.start * 8u, 0u}, exitst{0u, 0u};
-  uint32_t sum0 = 0, sum1 = 0, sum2 = 0;
   bool changed = active;
   if (launch > 0) {
     // nothing but a new state at the workgroup's first chunk can change anything in this launch
@@ -213,26 +255,24 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     if (!__syncthreads_or(c0)) return;
     entry = p.entry[gidx];
     exitst = p.exit[gidx];
-    const uint4 s = *(const uint4 *)(p.dcsum + 4u * (size_t)gidx);
-    sum0 = s.x, sum1 = s.y, sum2 = s.z;
     changed = c0;
     if (c0) entry = JbChunkState{ne.bitpos, ne.meta & 0xffffu};
   }
   load_tables(tab, p, img, tid);
-  if (tid < 16) ((uint32_t *)misc)[tid] = ((const uint32_t *)kZz2Dev)[tid];
   if (active) load_stream<Ly::kRows>(stream, p.scan + img.scan_off, g.start, tid);
 #pragma unroll
-  for (uint32_t i = 0; i < Ly::kNcp; i++)
-    cpst[i * L + tid] = launch > 0 ? (p.cps[i * n_all + gidx].state & 0xfffffu) : 0xffffffffu;
+  for (uint32_t i = 0; i < Ly::kNcp; i++) cpst[i * L + tid] = launch > 0 ? p.cps[i * n_all + gidx] : 0xffffffffu;
   __syncthreads();
 
   JbhCtx cx;
   cx.scol = stream + tid;
   cx.tab = tab;
-  cx.zz2 = (const uint8_t *)misc;
+  cx.zz2 = nullptr;
   cx.lut_ac = img.lut_ac, cx.lut_dc = img.lut_dc, cx.lut_comp = img.lut_comp;
   cx.nb4 = img.nb * 4u;
   cx.blk_bytes = img.blk_bytes;
+  cx.t2_first = img.n_tabs * kJbT1Entries;
+  uint32_t *const cpl = cpst + tid;  // this lane's checkpoints: cpl[i * L]
 
   for (int pass = 0; pass < kMaxPasses; pass++) {
     // (wave-uniform entry: a wave none of whose lanes changed goes straight to the barrier)
@@ -241,53 +281,39 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
       {
         const uint32_t bit = entry.bitpos < g.start * 8u ? g.start * 8u : entry.bitpos;
         const uint32_t u = jbh_u_of_bit(g.start, bit);
-        st.u = u < u_end ? u : u_end;
+        st.u = (changed && u < u_end) ? u : u_end;
         st.k = entry.meta & 0xffu;
         st.blk4 = ((entry.meta >> 8) & 0xffu) * 4u;
         if (st.k > 63u) st.k = 0;
         if (st.blk4 >= cx.nb4) st.blk4 = 0;
         st.nblk = 0;
       }
-      uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
-      bool live = changed && st.u < u_end;
-      bool met = false;
-      uint32_t met_i = 0;
-      while (live) {
+      uint32_t none = 0;
+      while (st.u < u_end) {
         const uint32_t up = st.u;
-        (void)jbh_step<false>(cx, st, dc0, dc1, dc2, nullptr, 0u);
-        live = st.u < u_end;
-        if (((st.u ^ up) >> 8) != 0) {  // a checkpoint: the first symbol boundary behind a multiple of 256 bits
-          const uint32_t i = (st.u >> 8) - 1u;
-          if (i < Ly::kNcp) {
-            const uint32_t s = jbh_pack_state(st);
-            if (live && cpst[i * L + tid] == s) {
-              met = true;  // the path of this chunk's previous decode: what follows is known
-              met_i = i;
-              live = false;
-            } else {
-              cpst[i * L + tid] = s;
-              *(uint4 *)(p.cps + i * n_all + gidx) = make_uint4(s | (st.nblk << 20), dc0, dc1, dc2);
-            }
-          }
+        (void)jbh_step<false>(cx, st, none, none, none, nullptr, 0u);
+        if (((st.u ^ up) >> 8) != 0) {
+          // a checkpoint: the first symbol boundary behind a multiple of 256 bits.  In the state recorded there (and
+          // still inside the chunk): the path of this chunk's previous decode -- what follows is known
+          uint32_t *rec = cpl + ((st.u >> 8) - 1u) * L;
+          const uint32_t s = jbh_pack_state(st), old = *rec;
+          const bool met = (st.u < u_end) & (((old ^ s) & 0xfffffu) == 0);  // (&: no branch)
+          *rec = met ? old : s;
+          st.u = met ? (kMet | ((st.u >> 8) - 1u)) : st.u;
         }
       }
+      JBH_TRACE_PASS_END(pass);
       if (changed) {
-        if (met) {
-          // the rest of the chunk is what the previous decode found: its exit state, its counts shifted by the
-          // difference of the counts at the meeting place; the later checkpoints move by the same amounts
-          const uint4 old = *(const uint4 *)(p.cps + met_i * n_all + gidx);
-          const uint32_t dn = st.nblk - (old.x >> 20), d0 = dc0 - old.y, d1 = dc1 - old.z, d2 = dc2 - old.w;
-          for (uint32_t i = met_i; i < Ly::kNcp; i++) {
-            uint4 *rec = (uint4 *)(p.cps + i * n_all + gidx);
-            const uint4 r = *rec;
-            *rec = make_uint4(r.x + (dn << 20), r.y + d0, r.z + d1, r.w + d2);
-          }
+        if (st.u >= kMet) {
+          // the rest of the chunk is what the previous decode found: its exit state, its block count shifted by the
+          // difference of the counts at the meeting place; the later checkpoints move by the same amount
+          const uint32_t met_i = st.u & 0xffu;
+          const uint32_t dn = st.nblk - (cpl[met_i * L] >> 20);
+          for (uint32_t i = met_i; i < Ly::kNcp; i++) cpl[i * L] += dn << 20;
           exitst.meta = (exitst.meta & 0xffffu) | ((((exitst.meta >> 16) + dn) & 0xffffu) << 16);
-          sum0 += d0, sum1 += d1, sum2 += d2;
         } else {
           exitst.bitpos = jbh_bit_of_u(g.start, st.u);
-          exitst.meta = st.k | ((st.blk4 >> 2) << 8) | ((st.nblk & 0xffffu) << 16);
-          sum0 = dc0, sum1 = dc1, sum2 = dc2;
+          exitst.meta = st.k | (st.blk4 << 6) | ((st.nblk & 0xffffu) << 16);
         }
       }
     }
@@ -307,14 +333,14 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   if (active) {
     p.entry[gidx] = entry;
     p.exit[gidx] = exitst;
-    *(uint4 *)(p.dcsum + 4u * (size_t)gidx) = make_uint4(sum0, sum1, sum2, 0u);
+#pragma unroll
+    for (uint32_t i = 0; i < Ly::kNcp; i++) p.cps[i * n_all + gidx] = cpl[i * L];
   }
   // what the workgroup's chunks add up to, for the writing pass
   Seg mine{0, 0, 0, 0, 0};
   if (active) {
     mine.f = g.first ? 1u : 0u;
     mine.n = (exitst.meta >> 16) + (g.first ? g.seg * img.ri * img.nb : 0u);
-    mine.d0 = sum0, mine.d1 = sum1, mine.d2 = sum2;
   }
   Seg total;
   (void)seg_scan_wg(mine, misc + 16, tid, &total);
@@ -322,7 +348,6 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / L;
     o->has_first = total.f;
     o->blocks = total.n;
-    o->dc[0] = total.d0, o->dc[1] = total.d1, o->dc[2] = total.d2;
   }
 }
 
@@ -348,19 +373,16 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   if (tid < 16) ((uint32_t *)misc)[tid] = ((const uint32_t *)kZz2Dev)[tid];
   if (active) load_stream<Ly::kRows>(stream, p.scan + img.scan_off, g.start, tid);
 
-  // where the chunk starts: the block, and the DC predictors there
+  // where the chunk starts: the state, and the block
   uint32_t err = 0;
   JbChunkState entry{g.start * 8u, 0u}, want{0u, 0u};
-  uint32_t block = g.seg * bpi, base0 = 0, base1 = 0, base2 = 0, want0 = 0, want1 = 0, want2 = 0;
+  uint32_t block = g.seg * bpi;
   if (img.needs_sync) {
     Seg mine{0, 0, 0, 0, 0};
     if (active) {
       want = p.exit[gidx];
-      const uint4 s = *(const uint4 *)(p.dcsum + 4u * (size_t)gidx);
-      want0 = s.x, want1 = s.y, want2 = s.z;
       mine.f = g.first ? 1u : 0u;
       mine.n = (want.meta >> 16) + (g.first ? g.seg * bpi : 0u);
-      mine.d0 = s.x, mine.d1 = s.y, mine.d2 = s.z;
       if (!g.first) {
         // the state this chunk starts from: its left neighbour's final exit state -- which must be the state the
         // synchronisation decoded this chunk from, or the chunks are not in step
@@ -370,45 +392,10 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
         if (en.bitpos != prev.bitpos || ((en.meta ^ prev.meta) & 0xffffu) != 0) err |= 4u;
       }
     }
-    // the workgroups of this image to the left, folded in order: the last one that holds an interval start counts
-    // from the image's first block, the ones behind it add up
-    const uint32_t w_first = img.wg0, w_me = img.wg0 + wg.first_chunk / L;
-    uint32_t *red = misc + 40;  // [0] index + 1 of the last workgroup with an interval start, [1..4] sums
-    if (tid < 8) red[tid] = 0;
-    __syncthreads();
-    uint32_t last_f = 0;
-    for (uint32_t w = w_first + tid; w < w_me; w += L)
-      if (p.wgsum[w].has_first) last_f = w - w_first + 1u;
-    if (last_f) atomicMax(&red[0], last_f);
-    __syncthreads();
-    const uint32_t from = red[0];  // (0: none of them; the image's first chunk starts an interval, so then w_me == w_first ... or the sums below are complete)
-    uint32_t a_n = 0, a0 = 0, a1 = 0, a2 = 0;
-    for (uint32_t w = w_first + tid; w < w_me; w += L) {
-      if (w - w_first + 1u >= from) {
-        const JbWgSum s = p.wgsum[w];
-        a_n += s.blocks, a0 += s.dc[0], a1 += s.dc[1], a2 += s.dc[2];
-      }
-    }
-    if (a_n) atomicAdd(&red[1], a_n);
-    if (a0) atomicAdd(&red[2], a0);
-    if (a1) atomicAdd(&red[3], a1);
-    if (a2) atomicAdd(&red[4], a2);
-    __syncthreads();
-    const Seg carry{from ? 1u : 0u, red[1], red[2], red[3], red[4]};
+    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / L, misc + 40, tid);
     Seg total;
-    const Seg incl = seg_scan_wg(mine, misc + 16, tid, &total);
-    // exclusive: what lies to the left of this lane
-    Seg left = seg_shfl_up(incl, 1);
-    if ((tid & 63u) == 0) {
-      // (the wave's first lane: the waves to the left, as seg_scan_wg left them in the scratch)
-      left = Seg{0, 0, 0, 0, 0};
-      for (uint32_t w = 0; w < (tid >> 6); w++) {
-        const uint32_t *s = misc + 16 + w * 5u;
-        left = seg_combine(left, Seg{s[0], s[1], s[2], s[3], s[4]});
-      }
-    }
-    left = seg_combine(carry, left);
-    if (!g.first) block = left.n, base0 = left.d0, base1 = left.d1, base2 = left.d2;
+    const Seg left = scan_left(mine, carry, misc + 16, tid, &total);
+    if (!g.first) block = left.n;
   }
   __syncthreads();
 
@@ -419,6 +406,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   cx.lut_ac = img.lut_ac, cx.lut_dc = img.lut_dc, cx.lut_comp = img.lut_comp;
   cx.nb4 = img.nb * 4u;
   cx.blk_bytes = img.blk_bytes;
+  cx.t2_first = img.n_tabs * kJbT1Entries;
 
   // the blocks of this chunk's interval end here (the padding bits behind them are not symbols)
   uint32_t block_end = (g.seg + 1u) * img.ri < img.n_mcus ? (g.seg + 1u) * bpi : img.n_mcus * img.nb;
@@ -435,7 +423,8 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
     if (st.blk4 >= cx.nb4) st.blk4 = 0;
     st.nblk = 0;
   }
-  uint32_t dc0 = base0, dc1 = base1, dc2 = base2;
+  const uint32_t k_in = st.k;
+  uint32_t dc0 = 0, dc1 = 0, dc2 = 0;
   uint8_t *const coef = (uint8_t *)p.coef + img.coef_off;
   bool live = active && st.u < u_end && block < block_end;
   while (live) {
@@ -446,20 +435,86 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
       live = st.u < u_end && block + st.nblk < block_end;
     }
   }
+  JBH_TRACE_PASS_END(0);
   if (active) {
     if (g.last) {
       // the interval's data ends before its blocks do, or its last symbol reaches beyond its last byte
       // (the host decoder's "entropy-coded data ends early": jb_frontend.cpp decode_interval)
       if (block + st.nblk != block_end || st.k != 0 || st.u > u_end || overran) err |= 2u;
     } else if (img.needs_sync) {
-      // this chunk must end where the synchronisation passes said it would, after as many blocks, and with the DC
-      // differences adding up to what they recorded (the predictors of the chunks behind it rest on those)
-      if (jbh_bit_of_u(g.start, st.u) != want.bitpos || (st.k | ((st.blk4 >> 2) << 8) | ((st.nblk & 0xffffu) << 16)) != want.meta ||
-          dc0 - base0 != want0 || dc1 - base1 != want1 || dc2 - base2 != want2)
-        err |= 4u;
+      // this chunk must end where the synchronisation passes said it would, after as many blocks
+      if (jbh_bit_of_u(g.start, st.u) != want.bitpos || (st.k | (st.blk4 << 6) | ((st.nblk & 0xffffu) << 16)) != want.meta) err |= 4u;
     }
     if (err) atomicOr(p.status + wg.image, err);
+    // the blocks whose DC symbol lies in this chunk hold DC DIFFERENCES: jb_huff_dc_kernel makes predictors of them
+    JbChunkDc o;
+    o.dc[0] = dc0, o.dc[1] = dc1, o.dc[2] = dc2;
+    o.first_block = block + (k_in != 0 ? 1u : 0u);
+    o.count = err ? 0u : st.nblk + (st.k != 0 ? 1u : 0u) - (k_in != 0 ? 1u : 0u);
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    p.chunk_dc[gidx] = o;
   }
+  if (img.needs_sync) {
+    // what the workgroup's DC differences add up to (behind its last interval start), for the chunks to the right
+    Seg mine{0, 0, 0, 0, 0};
+    if (active) mine = Seg{g.first ? 1u : 0u, 0u, dc0, dc1, dc2};
+    Seg total;
+    (void)seg_scan_wg(mine, misc + 16, tid, &total);
+    if (tid == 0) {
+      JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / L;
+      o->dc[0] = total.d0, o->dc[1] = total.d1, o->dc[2] = total.d2;
+    }
+  }
+}
+
+// ---- DC differences -> DC predictors (reference jpeg.cpp:335-345: component[0] = coeff + previousDC) --------
+// One lane per chunk again: the predictors at the chunk's start (0 at an interval's start: T.81 F.2.1.3.1,
+// reference jpeg.cpp:419-425) are a segmented prefix sum of the chunks' sums; the lane then walks the blocks whose
+// DC symbol lies in its chunk.  A predictor the coefficient format cannot hold is corrupt data (bit 0).
+__global__ __launch_bounds__(kJbHuffLanes) void jb_huff_dc_kernel(const JbHuffLaunch p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint32_t *const misc = (uint32_t *)lds;  // 256 bytes
+  const uint32_t tid = threadIdx.x;
+  const JbHuffWg wg = p.wgs[blockIdx.x];
+  const JbHuffImage img = p.images[wg.image];
+  const uint32_t ci = wg.first_chunk + tid;
+  const bool active = ci < img.n_chunks;
+  const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);
+  const bool first = (p.chunks[gidx].seg >> 31) != 0;
+  JbChunkDc cd = p.chunk_dc[gidx];
+  if (!active) cd.count = 0;
+  uint32_t p0 = 0, p1 = 0, p2 = 0;
+  if (img.needs_sync) {
+    Seg mine{0, 0, 0, 0, 0};
+    if (active) mine = Seg{first ? 1u : 0u, 0u, cd.dc[0], cd.dc[1], cd.dc[2]};
+    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / L, misc + 40, tid);
+    Seg total;
+    const Seg left = scan_left(mine, carry, misc + 16, tid, &total);
+    if (!first) p0 = left.d0, p1 = left.d1, p2 = left.d2;
+  }
+  uint8_t *const coef = (uint8_t *)p.coef + img.coef_off;
+  uint32_t pos4 = (cd.first_block % img.nb) * 4u;  // 4 * place of the block in its MCU
+  uint32_t bad = 0;
+  for (uint32_t i = 0; i < cd.count; i += 8) {
+    // (the loads of a batch first: they do not depend on each other)
+    int32_t diff[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) diff[q] = i + q < cd.count ? *(const int16_t *)(coef + (size_t)jbh_mul24(cd.first_block + i + q, img.blk_bytes)) : 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      if (i + q < cd.count) {
+        const uint32_t c = jbh_ubfe(img.lut_comp, pos4, 4);
+        const uint32_t pr = (c == 0 ? p0 : c == 1 ? p1 : p2) + (uint32_t)diff[q];
+        bad |= (pr + 32768u) > 65535u ? 1u : 0u;
+        p0 = c == 0 ? pr : p0;
+        p1 = c == 1 ? pr : p1;
+        p2 = c == 2 ? pr : p2;
+        *(int16_t *)(coef + (size_t)jbh_mul24(cd.first_block + i + q, img.blk_bytes)) = (int16_t)pr;
+        pos4 = pos4 + 4u == img.nb * 4u ? 0u : pos4 + 4u;
+      }
+    }
+  }
+  if (bad) atomicOr(p.status + wg.image, 1u);
 }
 
 // A small packed submission (one image) is fetched from the pinned host blob by a kernel instead of a
@@ -507,6 +562,7 @@ hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream) {
   if (p.n_wgs > 0) {
     if (small) hipLaunchKernelGGL(jb_huff_write_kernel<64>, dim3((unsigned)p.n_wgs), block, lds, stream, p);
     else hipLaunchKernelGGL(jb_huff_write_kernel<128>, dim3((unsigned)p.n_wgs), block, lds, stream, p);
+    hipLaunchKernelGGL(jb_huff_dc_kernel, dim3((unsigned)p.n_wgs), block, 256, stream, p);
   }
   return hipGetLastError();
 }

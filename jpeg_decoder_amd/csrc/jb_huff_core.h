@@ -52,9 +52,10 @@ JBH_FN int32_t jbh_sbfe(uint32_t v, uint32_t off, uint32_t width) {
 
 JBH_FN uint32_t jbh_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }  // (v_mul_u32_u24: a, b < 2^24)
 
-// (tools/huff_emu counts the steps)
+// (tools/huff_emu counts the steps, per lane and per pass)
 #ifndef JBH_TRACE_STEP
 #define JBH_TRACE_STEP() ((void)0)
+#define JBH_TRACE_PASS_END(pass) ((void)0)
 #endif
 
 constexpr uint32_t kJbhLanes = (uint32_t)kJbHuffLanes;
@@ -74,6 +75,7 @@ struct JbhCtx {            // what a lane's steps read besides its own state
   uint32_t lut_ac, lut_dc, lut_comp;  // JbHuffImage
   uint32_t nb4;            // 4 * blocks per MCU
   uint32_t blk_bytes;      // JbHuffImage (writing pass)
+  uint32_t t2_first;       // index of the first second-level entry in tab: n_tabs * kJbT1Entries
 };
 struct JbhLane {
   uint32_t u;              // position of the next symbol
@@ -87,45 +89,40 @@ struct JbhLane {
 
 // One symbol, without a branch (but the rare second-level lookup): with 64 lanes at 64 different places of their
 // blocks every path is taken by some lane in every step, so a path not taken saves nothing.
-// kStore == false (synchronisation): only the state moves and the DC differences are summed; bits that are no
+// kStore == false (synchronisation): only the state moves -- no magnitudes, no DC values; bits that are no
 // possible continuation of the state (the lane is out of step, or the data is corrupt -- which the writing pass will
 // report) move the lane on by one bit, to expect a block's start, at the NEXT place in the MCU: a wrong guess of
 // the block's place (luma tables on a chroma block) is what produces most impossible symbols and does not correct
 // itself.  kStore == true (writing pass): `coef` = the image's coefficient blocks, `block0` = the block the lane's
-// chunk starts in (an image the device decoder takes has fewer than 2^24 blocks, 2^32 bytes of them); after
-// impossible bits the state is not to be used.
+// chunk starts in (an image the device decoder takes has fewer than 2^24 blocks, 2^32 bytes of them); a DC symbol
+// stores its DIFFERENCE (jb_huff_dc_kernel turns the differences into predictors) and adds it to the chunk's sum
+// of its component; after impossible bits the state is not to be used.
 // Returns true for impossible bits.
 template <bool kStore>
 JBH_FN bool jbh_step(const JbhCtx &cx, JbhLane &st, uint32_t &dc0, uint32_t &dc1, uint32_t &dc2, uint8_t *coef, uint32_t block0) {
   JBH_TRACE_STEP();
   const uint32_t u = st.u;
-  const uint32_t j = u >> 5;
+  const uint32_t j = jbh_ubfe(u, 5, 27);
   const uint32_t w = jbh_alignbit(cx.scol[j * kJbhLanes], cx.scol[j * kJbhLanes + kJbhLanes], ~u);
   const bool isdc = st.k == 0;
   const uint32_t tix = jbh_ubfe(isdc ? cx.lut_dc : cx.lut_ac, st.blk4, 4);
   uint32_t e = cx.tab[(tix << kJbT1Bits) + (w >> (32 - kJbT1Bits))];
-  if ((e & 31u) == 0 && e != 0)  // a code longer than the first level resolves: the entry names its second-level table
-    e = cx.tab[(e << 1) + ((w >> 16) & (kJbT2Entries - 1u))];
+  if (e - 1u < 31u)  // a code longer than the first level resolves: the entry names its second-level table
+    e = cx.tab[cx.t2_first + ((e - 1u) << kJbT2Bits) + ((w >> 16) & (kJbT2Entries - 1u))];
   const uint32_t total = e & 31u, size = (e >> 5) & 15u, adv = e >> 9;
   const uint32_t k1 = st.k + adv;
   // no code here, or a run that leaves the block (reference jpeg.cpp:372 "Invalid AC length": k + run >= 64)
-  bool bad = total == 0 || (k1 - 65u) < 17u;
-  // EXTEND without a branch: x = the magnitude bits read as a signed field; a field that starts with 1 stands for
-  // itself (x + 2^size), one that starts with 0 for x - (2^size - 1)
-  const int32_t x = jbh_sbfe(w, 32u - total, size);
-  int32_t val = x - (int32_t)(((1u << size) - 1u) ^ (uint32_t)(x >> 31));
-  {
-    const uint32_t c = jbh_ubfe(cx.lut_comp, st.blk4, 4);
-    // (unsigned: the sums of a lane that is out of step are garbage and may wrap)
-    const uint32_t pr = (c == 0 ? dc0 : c == 1 ? dc1 : dc2) + (uint32_t)val;
-    if (kStore) bad |= isdc && (pr + 32768u) > 65535u;  // a predictor the coefficient format cannot hold
-    const bool upd = isdc && !bad;
-    dc0 = (upd && c == 0) ? pr : dc0;
-    dc1 = (upd && c == 1) ? pr : dc1;
-    dc2 = (upd && c == 2) ? pr : dc2;
-    if (kStore) val = isdc ? (int32_t)pr : val;
-  }
+  const bool bad = e == 0 || (k1 - 65u) < 17u;
   if (kStore) {
+    // EXTEND without a branch: x = the magnitude bits read as a signed field; a field that starts with 1 stands for
+    // itself (x + 2^size), one that starts with 0 for x - (2^size - 1)
+    const int32_t x = jbh_sbfe(w, 32u - total, size);
+    const int32_t val = x - (int32_t)(((1u << size) - 1u) ^ (uint32_t)(x >> 31));
+    const uint32_t c = jbh_ubfe(cx.lut_comp, st.blk4, 4);
+    const uint32_t dcv = (isdc && !bad) ? (uint32_t)val : 0u;
+    dc0 += c == 0 ? dcv : 0u;
+    dc1 += c == 1 ? dcv : 0u;
+    dc2 += c == 2 ? dcv : 0u;
     if (!bad && (isdc || size != 0))  // (k1 - 1 = k + run, 0 for DC)
       *(int16_t *)(coef + (jbh_mul24(block0 + st.nblk, cx.blk_bytes) + cx.zz2[k1 - 1u])) = (int16_t)val;
   }
@@ -140,7 +137,7 @@ JBH_FN bool jbh_step(const JbhCtx &cx, JbhLane &st, uint32_t &dc0, uint32_t &dc1
   return bad;
 }
 
-JBH_FN uint32_t jbh_pack_state(const JbhLane &st) { return st.u | (st.k << 11) | ((st.blk4 >> 2) << 17); }
+JBH_FN uint32_t jbh_pack_state(const JbhLane &st) { return st.u | (st.k << 11) | (st.blk4 << 15) | (st.nblk << 20); }  // (blk4 <= 20: bits 15..19)
 
 // ---- host: table construction ---------------------------------------------------------------------
 #include <string.h>
@@ -181,11 +178,7 @@ inline bool jb_huff_fill_table_impl_(const uint8_t counts[17], const uint8_t *sy
           sub_of_prefix = (int32_t)(*n_t2)++;
           sub_prefix = prefix;
           memset(set->t2[sub_of_prefix], 0, sizeof set->t2[0]);
-          // the entry names the second-level table by its place in LDS, where the n_tabs first-level tables in use
-          // lie in front of the pool: index of its first entry / 2 (total = 0, non-zero)
-          const uint32_t first_entry = n_tabs * kJbT1Entries + (uint32_t)sub_of_prefix * kJbT2Entries;
-          t1[prefix] = (uint16_t)(first_entry >> 1);
-          if ((first_entry >> 1) & 31u) return false;  // (cannot happen: multiples of 64)
+          t1[prefix] = (uint16_t)(sub_of_prefix + 1);  // 1..24: no symbol's entry is that small (adv >= 1: 512 and up)
         }
         const uint32_t rest = len - kJbT1Bits;  // bits of the code behind the prefix
         const uint32_t first = (code & ((1u << rest) - 1u)) << (kJbT2Bits - rest);

@@ -3,8 +3,11 @@
 // with the host decoder (jb_entropy_decode, itself pinned to the reference's coefficient dumps).
 // Test infrastructure: checks the kernels' logic where there is no GPU, and counts what the
 // synchronisation costs (steps per pass) for design work.  Not part of the product.
-//   huff_emu [--launches N] [--quiet] file.jpg [file.jpg ...]     (all files in ONE submission)
-// exit code 0: every image's coefficients equal the host decoder's (or both reject it)
+//   huff_emu [--launches N] [--quiet] [--strict] file.jpg [file.jpg ...]     (all files in ONE submission)
+// exit code 0: whatever the kernels accept (status 0) the host decoder accepts too, with the same coefficients.
+// An image the kernels flag goes back to the host decoder in the product, so a flag on a stream the host
+// accepts is allowed (damaged streams with bytes behind an interval's last block, say) -- unless --strict:
+// then every image the host decoder accepts must come through with status 0 (undamaged files).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -12,16 +15,53 @@
 #include <string>
 #include <vector>
 
-static std::atomic<long long> g_steps{0};
-#define JBH_TRACE_STEP() (g_steps.fetch_add(1, std::memory_order_relaxed))
+#include <map>
+#include <mutex>
+// steps of this lane since its last pass ended; the passes of this lane in this kernel
+static thread_local uint32_t tl_steps = 0;
+static thread_local std::vector<uint32_t> tl_passes;
+#define JBH_TRACE_STEP() (tl_steps++)
+static thread_local std::vector<int> tl_pass_no;
+#define JBH_TRACE_PASS_END(pass) (tl_passes.push_back(tl_steps), tl_pass_no.push_back((int)(pass)), tl_steps = 0)
 
 #include "../../jpeg_decoder_amd/csrc/jb_huff.hip"
 
 alignas(16) uint8_t lds[160 * 1024];
+// per launch (in order): lane-steps, and wave-steps = sum over the waves' passes of the longest lane (what a wave pays)
+static std::mutex g_mu;
+static int g_launch = -1;
+static std::map<std::pair<int, int>, std::vector<uint32_t>> g_wave_max;  // (block, wave) -> per pass: max over lanes
+static std::vector<long long> g_lane_steps, g_wave_steps, g_wave_passes;
+struct PassStat {
+  long long lanes = 0, steps = 0, hist[5] = {0, 0, 0, 0, 0};
+};
+static std::map<std::pair<int, int>, PassStat> g_by_pass;  // (launch, pass)
+static void emu_merge(unsigned b, unsigned t) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto &v = g_wave_max[{(int)b, (int)(t >> 6)}];
+  if (v.size() < tl_passes.size()) v.resize(tl_passes.size(), 0);
+  for (size_t i = 0; i < tl_passes.size(); i++) {
+    g_lane_steps[(size_t)g_launch] += tl_passes[i];
+    if (tl_passes[i] > v[i]) v[i] = tl_passes[i];
+    auto &ps = g_by_pass[{g_launch, tl_pass_no[i]}];
+    if (tl_passes[i]) ps.lanes++, ps.steps += tl_passes[i];
+    const unsigned bucket = tl_passes[i] == 0 ? 0 : tl_passes[i] < 32 ? 1 : tl_passes[i] < 64 ? 2 : tl_passes[i] < 128 ? 3 : 4;
+    ps.hist[bucket]++;
+  }
+}
 namespace emu {
 thread_local Idx tl_thread, tl_block, tl_grid;
 thread_local Group *tl_group = nullptr;
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  g_launch++;
+  g_lane_steps.push_back(0), g_wave_steps.push_back(0), g_wave_passes.push_back(0);
+  g_wave_max.clear();
+  struct Sum {
+    ~Sum() {
+      for (auto &kv : g_wave_max)
+        for (uint32_t m : kv.second) g_wave_steps[(size_t)g_launch] += m, g_wave_passes[(size_t)g_launch] += m ? 1 : 0;
+    }
+  } sum_at_exit;
   for (unsigned b = 0; b < grid.x; b++) {
     Group group((int)block.x);
     std::vector<std::thread> th;
@@ -31,7 +71,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         tl_block.x = b;
         tl_grid.x = grid.x;
         tl_group = &group;
+        tl_steps = 0;
+        tl_passes.clear();
+        tl_pass_no.clear();
         body();
+        emu_merge(b, t);
         // a lane that returns early still has to let the others through their barriers: the kernels
         // only return uniformly, so nothing to do here
       });
@@ -53,11 +97,12 @@ static std::vector<uint8_t> read_file(const char *path) {
 
 int main(int argc, char **argv) {
   int launches = kJbSyncLaunches;
-  bool quiet = false;
+  bool quiet = false, strict = false;
   std::vector<const char *> paths;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--launches") && i + 1 < argc) launches = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
+    else if (!strcmp(argv[i], "--strict")) strict = true;
     else paths.push_back(argv[i]);
   }
   if (paths.empty()) {
@@ -111,8 +156,8 @@ int main(int argc, char **argv) {
   p.chunks = (const JbChunkDesc *)(d + lay.off_chunks);
   p.entry = (JbChunkState *)(d + lay.off_entry);
   p.exit = (JbChunkState *)(d + lay.off_exit);
-  p.cps = (JbCheckpoint *)(d + lay.off_cps);
-  p.dcsum = (uint32_t *)(d + lay.off_dcsum);
+  p.cps = (uint32_t *)(d + lay.off_cps);
+  p.chunk_dc = (JbChunkDc *)(d + lay.off_chunk_dc);
   p.wgsum = (JbWgSum *)(d + lay.off_wgsum);
   p.n_chunks_total = lay.n_chunks;
   p.sync_launches = launches;
@@ -130,8 +175,8 @@ int main(int argc, char **argv) {
     size_t diff = 0, first = 0;
     if (hrc == JB_OK)
       for (size_t k = 0; k < want.size(); k++)
-        if (got[k] != want[k] && !diff++) first = k;
-    const bool ok = hrc == JB_OK ? (status[(size_t)i] == 0 && diff == 0) : status[(size_t)i] != 0;
+        if (got[k] != want[k]) { if (!diff++) first = k; if (getenv("EMU_DIFFS") && diff < 40) printf("  block %zu idx %zu got %d want %d\n", k / 64, k % 64, got[k], want[k]); }
+    const bool ok = hrc == JB_OK ? (status[(size_t)i] == 0 ? diff == 0 : !strict) : status[(size_t)i] != 0;
     if (!ok) bad++;
     if (!quiet || !ok)
       printf("%s: %ux%u %dx%d, %u chunks of %u bytes in %u workgroups, sync %u: status %u, host rc %d, %zu coefficients differ%s -> %s\n", paths[(size_t)i],
@@ -139,6 +184,14 @@ int main(int argc, char **argv) {
              (j.img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes, j.img.needs_sync, status[(size_t)i], hrc, diff,
              diff ? (" (first at " + std::to_string(first) + ")").c_str() : "", ok ? "ok" : "MISMATCH");
   }
-  if (!quiet) printf("steps: %lld\n", g_steps.load());
+  if (!quiet)
+    for (size_t l = 0; l < g_lane_steps.size(); l++)
+      printf("launch %zu: %lld lane-steps, %lld wave-steps in %lld wave-passes (64 x wave-steps = %.2f x lane-steps)\n", l, g_lane_steps[l], g_wave_steps[l],
+             g_wave_passes[l], g_lane_steps[l] ? 64.0 * (double)g_wave_steps[l] / (double)g_lane_steps[l] : 0.0);
+  if (!quiet && getenv("EMU_PASSES"))
+    for (auto &kv : g_by_pass)
+      printf("  launch %d pass %3d: %6lld lanes decode, %8lld steps (mean %5.1f); lanes by steps: idle %lld, <32 %lld, <64 %lld, <128 %lld, more %lld\n", kv.first.first,
+             kv.first.second, kv.second.lanes, kv.second.steps, kv.second.lanes ? (double)kv.second.steps / (double)kv.second.lanes : 0.0, kv.second.hist[0],
+             kv.second.hist[1], kv.second.hist[2], kv.second.hist[3], kv.second.hist[4]);
   return bad ? 1 : 0;
 }

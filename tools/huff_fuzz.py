@@ -75,7 +75,7 @@ def main():
             assert np.array_equal(cd, jb.entropy_decode(bytes(s))[2])
         while time.time() - t0 < args.seconds:
             # files with restart intervals: either device decoder (jb_huff_prepare_ reads the knob per image)
-            os.environ["JPEGBLK_HUFF_MODE"] = ("interval", "chunk")[int(rng.integers(0, 2))]
+            os.environ["JPEGBLK_CHUNK_BYTES"] = ("64", "128")[int(rng.integers(0, 2))]
             data = mutate(rng, base[int(rng.integers(0, len(base)))])
             try:
                 _, _, cd = ctx.entropy_decode_device(data)
@@ -102,7 +102,7 @@ def main():
                         except OSError:
                             pass
     total = sum(counts.values())
-    os.environ.pop("JPEGBLK_HUFF_MODE", None)
+    os.environ.pop("JPEGBLK_CHUNK_BYTES", None)
     print(f"huff fuzz ok (files with DRI through either device decoder at random): {total} mutants, statuses {dict(sorted(counts.items()))}, {agree} accepted by both decoders and equal, {lenient} accepted by the device decoder alone")
     assert lenient == 0, "the device decoder accepted streams the host decoder rejects (saved under gpurun_out/)"
 
