@@ -1021,7 +1021,7 @@ int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%
 size_t jb_huff_pack_size_(const JbHuffJob *const *jobs, int n) {
   size_t n_wg = 0, n_starts = 0, scan_bytes = 0, n_chunks = 0;
   for (int i = 0; i < n; i++) {
-    n_wg += (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+    n_wg += (jobs[i]->img.n_chunks + kJbOwnChunks - 1) / kJbOwnChunks;
     n_chunks += jobs[i]->img.n_chunks;
     n_starts += jobs[i]->starts.size();
     scan_bytes += ((jobs[i]->scan.size() + 15) & ~(size_t)15);
@@ -1047,7 +1047,7 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
       sets.push_back(i);
     }
     set_of[(size_t)i] = found;
-    const size_t wgs = (jobs[i]->img.n_chunks + kJbHuffLanes - 1) / kJbHuffLanes;
+    const size_t wgs = (jobs[i]->img.n_chunks + kJbOwnChunks - 1) / kJbOwnChunks;
     n_wg += wgs;
     if (jobs[i]->img.needs_sync) n_sync_wg += wgs;
     n_chunks += jobs[i]->img.n_chunks;
@@ -1104,7 +1104,7 @@ int jb_huff_pack_(const JbHuffJob *const *jobs, int n, int64_t coef_stride, uint
     }
     if (c != j.img.n_chunks) return JB_ERR_STATE;
     chunk0 += j.img.n_chunks;
-    for (uint32_t f = 0; f < j.img.n_chunks; f += kJbHuffLanes) {
+    for (uint32_t f = 0; f < j.img.n_chunks; f += kJbOwnChunks) {
       wg[w++] = JbHuffWg{(uint32_t)i, f};
       if (j.img.needs_sync) swg[sw++] = JbHuffWg{(uint32_t)i, f};
     }

@@ -59,13 +59,20 @@ struct JbHuffImage {
   uint32_t n_tabs;     // first-level tables of its table set (AC slots first, then DC slots: lut_dc counts from the number of AC slots)
 };
 
-struct JbHuffWg {  // one workgroup = up to kJbHuffLanes consecutive chunks of one image
+struct JbHuffWg {  // one workgroup OWNS up to kJbOwnChunks consecutive chunks of one image
   uint32_t image;
   uint32_t first_chunk;
 };
 
 constexpr uint32_t kJbChunkBytes = 128;  // bytes of clean scan per lane, at most (JbHuffImage::chunk_bytes)
-constexpr int kJbHuffLanes = 256;        // chunks per workgroup
+constexpr int kJbHuffLanes = 256;        // lanes per workgroup
+// A workgroup of the synchronisation decodes the kJbWarmChunks chunks in front of the ones it owns as well: its first
+// own chunk then starts from a state that has had eight chunks to fall into step -- so the exit state its left
+// neighbour arrives at for the same chunk is, as a rule, the one it already started from, and the second launch finds
+// nothing to do (it still runs: it is what makes the result right when the rule fails).  All three kernels cut an image
+// the same way, so that the workgroups' sums line up: the writing pass and the DC pass leave those lanes idle (3 %).
+constexpr uint32_t kJbWarmChunks = 8;
+constexpr uint32_t kJbOwnChunks = kJbHuffLanes - kJbWarmChunks;
 constexpr int kJbSyncLaunches = 2;       // synchronisation launches before the writing pass (which verifies).  The lanes
                                          // of a workgroup fall into step with each other inside ONE launch (passes over
                                          // LDS, until nothing changes); a further launch carries the exit state of a

@@ -234,9 +234,12 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
   const uint32_t tid = threadIdx.x;
   const JbHuffWg wg = p.sync_wgs[blockIdx.x];
   const JbHuffImage img = p.images[wg.image];
-  const uint32_t ci = wg.first_chunk + tid;
-  const bool active = ci < img.n_chunks;
-  const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);  // (idle lanes: valid addresses, nothing stored)
+  // lanes 0..kJbWarmChunks-1: the chunks in front of the workgroup's own (none in front of an image's first chunk)
+  const uint32_t ci = wg.first_chunk + tid - kJbWarmChunks;  // (wraps below 0 for the lanes in front of chunk 0)
+  const bool owned = tid >= kJbWarmChunks && ci < img.n_chunks;
+  // (the warm-up lanes only matter for the first launch: afterwards the own chunks' states come from device memory)
+  const bool active = ci < img.n_chunks && (owned || launch == 0);
+  const uint32_t gidx = img.state_off + (ci < img.n_chunks ? ci : img.n_chunks - 1u);  // (idle lanes: valid addresses, nothing stored)
   const ChunkGeo g = chunk_geo(p, img, gidx);
   const uint32_t u0 = jbh_u_of_bit(g.start, g.start * 8u), u_end = u0 + (g.end - g.start) * 8u;
   const size_t n_all = p.n_chunks_total;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     // nothing but a new state at the workgroup's first chunk can change anything in this launch
     bool c0 = false;
     JbChunkState ne{0u, 0u};
-    if (tid == 0 && !g.first) {
+    if (tid == kJbWarmChunks && owned && !g.first) {
       ne = p.exit[gidx - 1u];
       const JbChunkState en = p.entry[gidx];
       c0 = ne.bitpos != en.bitpos || ((ne.meta ^ en.meta) & 0xffffu) != 0;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     xmeta[tid] = exitst.meta & 0xffffu;
     __syncthreads();
     changed = false;
-    if (active && !g.first && tid > 0) {
+    if (active && !g.first && tid > (launch == 0 ? 0u : kJbWarmChunks)) {
       const uint32_t nbit = xbit[tid - 1u], nmeta = xmeta[tid - 1u];
       if (nbit != entry.bitpos || nmeta != (entry.meta & 0xffffu)) {
         entry = JbChunkState{nbit, nmeta};
@@ -330,22 +333,22 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_sync_kernel(const JbHuff
     }
     if (!__syncthreads_or(changed)) break;
   }
-  if (active) {
+  if (owned) {
     p.entry[gidx] = entry;
     p.exit[gidx] = exitst;
 #pragma unroll
     for (uint32_t i = 0; i < Ly::kNcp; i++) p.cps[i * n_all + gidx] = cpl[i * L];
   }
-  // what the workgroup's chunks add up to, for the writing pass
+  // what the workgroup's own chunks add up to, for the writing pass
   Seg mine{0, 0, 0, 0, 0};
-  if (active) {
+  if (owned) {
     mine.f = g.first ? 1u : 0u;
     mine.n = (exitst.meta >> 16) + (g.first ? g.seg * img.ri * img.nb : 0u);
   }
   Seg total;
   (void)seg_scan_wg(mine, misc + 16, tid, &total);
   if (tid == 0) {
-    JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / L;
+    JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / kJbOwnChunks;
     o->has_first = total.f;
     o->blocks = total.n;
   }
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
   const JbHuffWg wg = p.wgs[blockIdx.x];
   const JbHuffImage img = p.images[wg.image];
   const uint32_t ci = wg.first_chunk + tid;
-  const bool active = ci < img.n_chunks;
+  const bool active = tid < kJbOwnChunks && ci < img.n_chunks;
   const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);
   const ChunkGeo g = chunk_geo(p, img, gidx);
   const uint32_t u0 = jbh_u_of_bit(g.start, g.start * 8u), u_end = u0 + (g.end - g.start) * 8u;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
         if (en.bitpos != prev.bitpos || ((en.meta ^ prev.meta) & 0xffffu) != 0) err |= 4u;
       }
     }
-    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / L, misc + 40, tid);
+    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / kJbOwnChunks, misc + 40, tid);
     Seg total;
     const Seg left = scan_left(mine, carry, misc + 16, tid, &total);
     if (!g.first) block = left.n;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_write_kernel(const JbHuf
     Seg total;
     (void)seg_scan_wg(mine, misc + 16, tid, &total);
     if (tid == 0) {
-      JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / L;
+      JbWgSum *o = p.wgsum + img.wg0 + wg.first_chunk / kJbOwnChunks;
       o->dc[0] = total.d0, o->dc[1] = total.d1, o->dc[2] = total.d2;
     }
   }
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_dc_kernel(const JbHuffLa
   const JbHuffWg wg = p.wgs[blockIdx.x];
   const JbHuffImage img = p.images[wg.image];
   const uint32_t ci = wg.first_chunk + tid;
-  const bool active = ci < img.n_chunks;
+  const bool active = tid < kJbOwnChunks && ci < img.n_chunks;
   const uint32_t gidx = img.state_off + (active ? ci : img.n_chunks - 1u);
   const bool first = (p.chunks[gidx].seg >> 31) != 0;
   JbChunkDc cd = p.chunk_dc[gidx];
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kJbHuffLanes) void jb_huff_dc_kernel(const JbHuffLa
   if (img.needs_sync) {
     Seg mine{0, 0, 0, 0, 0};
     if (active) mine = Seg{first ? 1u : 0u, 0u, cd.dc[0], cd.dc[1], cd.dc[2]};
-    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / L, misc + 40, tid);
+    const Seg carry = fold_left_workgroups(p, img.wg0, img.wg0 + wg.first_chunk / kJbOwnChunks, misc + 40, tid);
     Seg total;
     const Seg left = scan_left(mine, carry, misc + 16, tid, &total);
     if (!first) p0 = left.d0, p1 = left.d1, p2 = left.d2;
