@@ -8,6 +8,11 @@
 // the pixels of image i travel device->host while the coefficients of image i+1 travel
 // host->device (the link is full duplex: 57 GB/s one way, 97 GB/s both ways, tools/probe_pcie.hip).  There is deliberately NO CPU
 // fallback here: without a usable HIP device every compute entry point fails with JB_ERR_HIP.
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdarg>
@@ -58,8 +63,23 @@ struct Slot {
   int n_status = 0;              // images of the submission in flight whose status words must be checked
   hipEvent_t computed = nullptr;  // kernel finished (upload stream) -> the download may start
   hipEvent_t done = nullptr;      // pixels are in the caller's buffer
+  // a download that the context's download thread has not issued yet (see jb_ctx::dl_*): `done` is only recorded
+  // once it has, so whoever waits for the slot waits for this to clear first
+  std::atomic<int> dl_pending{0};
   bool busy = false;
   int ticket = -1;
+};
+
+// one download handed to the context's download thread
+struct DlItem {
+  Slot *slot;
+  void *dst;
+  const void *src;
+  size_t bytes;                                    // 1-D copy ...
+  size_t dst_pitch, src_pitch, row_bytes, rows;    // ... or, rows > 0, a 2-D one
+  void *status_dst;
+  const void *status_src;
+  size_t status_bytes;
 };
 
 }  // namespace
@@ -97,6 +117,19 @@ struct jb_ctx {
   long long n_device_entropy = 0;  // images whose entropy stage ran on the device (jb_huff.hip)
   jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
+  // Downloads of the submissions whose entropy stage runs on the device, in the order their KERNELS FINISH, back to
+  // back on one stream.  Issued by the submitting threads on their own streams, several copies shared the link at
+  // once (45 GB/s while busy against the 57 GB/s one stream gets); on one dedicated stream in SUBMISSION order a copy
+  // whose kernels were still queued held up every copy behind it.  So the submitter records `computed` behind its
+  // kernels and hands the copy to this thread, which issues whichever is ready, two deep.
+  std::thread dl_thread;
+  std::mutex dl_mu;
+  std::condition_variable dl_cv, dl_issued_cv;
+  std::deque<DlItem> dl_queue;
+  bool dl_stop = false;
+  int dl_busy = 0;  // items taken off the queue whose copies are being issued
+  hipStream_t dl_stream = nullptr;
+  std::string dl_error;
 };
 
 namespace {
@@ -162,14 +195,93 @@ hipError_t build_ring(jb_ctx *ctx) {
 // threads: no gain on 1,024 1080p or 64 8192x8192 files, 2-4 % slower on 8,192 small images and on
 // the host-entropy path, where the queries under the shared lock cost more than the rare wait:
 // profiles/r02b/ab_ring_order.txt.)
+// the submission in slot `s` has completed: its download has been issued (by the download thread, if it went
+// that way) and has finished
+int slot_finish(jb_ctx *ctx, Slot &s) {
+  if (s.dl_pending.load(std::memory_order_acquire)) {
+    std::unique_lock<std::mutex> lk(ctx->dl_mu);
+    ctx->dl_issued_cv.wait(lk, [&] { return s.dl_pending.load(std::memory_order_acquire) == 0; });
+    if (!ctx->dl_error.empty()) return fail(ctx, JB_ERR_HIP, "%s", ctx->dl_error.c_str());
+  }
+  JB_HIP(ctx, hipEventSynchronize(s.done));
+  return JB_OK;
+}
+
 int take_slot(jb_ctx *ctx, Slot **out) {
   Slot &s = ctx->slots[ctx->next_slot];
   if (s.busy) {
-    JB_HIP(ctx, hipEventSynchronize(s.done));
+    const int rc = slot_finish(ctx, s);
+    if (rc) return rc;
     s.busy = false;
   }
   *out = &s;
   return JB_OK;
+}
+
+void dl_thread_main(jb_ctx *ctx) {
+  (void)hipSetDevice(ctx->device);
+  std::deque<hipEvent_t> inflight;  // `done` events of the copies issued and not known to have finished
+  for (;;) {
+    DlItem it;
+    bool have = false;
+    {
+      std::unique_lock<std::mutex> lk(ctx->dl_mu);
+      ctx->dl_cv.wait(lk, [&] { return ctx->dl_stop || !ctx->dl_queue.empty(); });
+      if (ctx->dl_stop && ctx->dl_queue.empty()) return;
+      for (auto q = ctx->dl_queue.begin(); q != ctx->dl_queue.end(); ++q) {
+        const hipError_t e = hipEventQuery(q->slot->computed);
+        if (e != hipErrorNotReady) {  // finished (or failed: the copy below will say so)
+          it = *q;
+          ctx->dl_queue.erase(q);
+          ctx->dl_busy++;
+          have = true;
+          break;
+        }
+      }
+      (void)hipGetLastError();  // (hipErrorNotReady is not an error of this thread's next call)
+    }
+    if (!have) {
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+      continue;
+    }
+    // two copies deep: the engine always has the next one, and nothing queues up behind a slow host
+    while (inflight.size() >= 2) {
+      (void)hipEventSynchronize(inflight.front());
+      inflight.pop_front();
+    }
+    hipError_t e;
+    if (it.rows) e = hipMemcpy2DAsync(it.dst, it.dst_pitch, it.src, it.src_pitch, it.row_bytes, it.rows, hipMemcpyDeviceToHost, ctx->dl_stream);
+    else e = hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, ctx->dl_stream);
+    if (e == hipSuccess && it.status_bytes) e = hipMemcpyAsync(it.status_dst, it.status_src, it.status_bytes, hipMemcpyDeviceToHost, ctx->dl_stream);
+    if (e == hipSuccess) e = hipEventRecord(it.slot->done, ctx->dl_stream);
+    inflight.push_back(it.slot->done);
+    {
+      std::lock_guard<std::mutex> lk(ctx->dl_mu);
+      if (e != hipSuccess && ctx->dl_error.empty()) ctx->dl_error = std::string("download thread: ") + hipGetErrorString(e);
+      it.slot->dl_pending.store(0, std::memory_order_release);
+      ctx->dl_busy--;
+    }
+    ctx->dl_issued_cv.notify_all();
+  }
+}
+
+// hand a download to the download thread (started on first use); the caller has recorded item.slot->computed
+int dl_enqueue(jb_ctx *ctx, const DlItem &item) {
+  if (!ctx->dl_stream) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->dl_stream, hipStreamNonBlocking));
+  item.slot->dl_pending.store(1, std::memory_order_release);
+  {
+    std::lock_guard<std::mutex> lk(ctx->dl_mu);
+    if (!ctx->dl_thread.joinable()) ctx->dl_thread = std::thread(dl_thread_main, ctx);
+    ctx->dl_queue.push_back(item);
+  }
+  ctx->dl_cv.notify_one();
+  return JB_OK;
+}
+
+// every download handed over has been issued
+void dl_drain(jb_ctx *ctx) {
+  std::unique_lock<std::mutex> lk(ctx->dl_mu);
+  ctx->dl_issued_cv.wait(lk, [&] { return ctx->dl_queue.empty() && ctx->dl_busy == 0; });
 }
 
 int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
@@ -239,6 +351,19 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
 void jb_ctx_destroy(jb_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
+  if (ctx->dl_thread.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(ctx->dl_mu);
+      ctx->dl_stop = true;
+    }
+    ctx->dl_cv.notify_all();
+    ctx->dl_thread.join();
+  }
+  if (ctx->dl_stream) {
+    (void)hipStreamSynchronize(ctx->dl_stream);
+    (void)hipStreamDestroy(ctx->dl_stream);
+    ctx->dl_stream = nullptr;
+  }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (hipStream_t &ps : ctx->pool)
@@ -286,6 +411,8 @@ void *jb_ctx_stream(jb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int jb_ctx_synchronize(jb_ctx *ctx) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_synchronize: ctx is NULL");
   DeviceGuard guard(ctx->device);
+  dl_drain(ctx);
+  if (ctx->dl_stream) JB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
@@ -368,6 +495,8 @@ int jb_ctx_reserve(jb_ctx *ctx, size_t max_coef_bytes, size_t max_rgb_bytes) {
   if (ctx->n_slots > 0 && max_coef_bytes <= ctx->max_coef && max_rgb_bytes <= ctx->max_rgb) return JB_OK;
   DeviceGuard guard(ctx->device);
   // nothing may be in flight while the slots' buffers are replaced
+  dl_drain(ctx);
+  if (ctx->dl_stream) JB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
@@ -647,18 +776,7 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   // the whole submission on one stream of the pool, consecutive submissions on different ones
   hipStream_t &ps = ctx->pool[ctx->n_group_submits++ % jb_ctx::kPool];
   if (!ps) JB_HIP(ctx, hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-  hipStream_t up = ps, down = ps;
-  // (downloads of these submissions on 1..4 dedicated download streams instead, JPEGBLK_DEV_DOWN=N: +12-15 %
-  // with one or two on 1,024 1080p files, -20 to -45 % on 8192x8192 files with any number, where a
-  // download that waits for its kernels holds up the ones queued behind it: not taken;
-  // profiles/r02b/ab_dev_download_stream.txt)
-  static const int n_down = getenv("JPEGBLK_DEV_DOWN") ? atoi(getenv("JPEGBLK_DEV_DOWN")) : 0;  // N dedicated download streams (0: the submission's own)
-  if (n_down == 1 && ctx->stream2) down = ctx->stream2;
-  else if (n_down > 1) {
-    const int k = 1 + (int)((ctx->n_group_submits - 1) % (unsigned)(n_down < jb_ctx::kMaxPairs ? n_down : jb_ctx::kMaxPairs - 1));
-    if (!ctx->pair_down[k]) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pair_down[k], hipStreamNonBlocking));
-    down = ctx->pair_down[k];
-  }
+  hipStream_t up = ps;
   for (int i = 0; i < n_images; i++) {
     rc = jb_resolve_qtabs(desc, jobs ? jobs[i]->qtabs : qtabs_in + (size_t)i * 256, s.h_q + (size_t)i * 192);
     if (rc) return fail(ctx, rc, "bad quantisation table id");
@@ -694,25 +812,37 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   b.rgb_image_stride = g.rgb_bytes;
   rc = jb_blocks_to_rgb_device(ctx, &b, up);
   if (rc) return rc;
-  if (dst_device) {
-    down = up;  // the pixels stay on the device; only the status words come back
-  } else {
-    if (down != up) {
-      JB_HIP(ctx, hipEventRecord(s.computed, up));
-      JB_HIP(ctx, hipStreamWaitEvent(down, s.computed, 0));
-    }
-    if (rgb_stride == dev_stride)
-      JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, down));
-    else
-      JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
-                                   (size_t)desc->height, hipMemcpyDeviceToHost, down));
-  }
   // the status words travel with the pixels: into the caller's (pinned) words when it keeps its own
   // -- many threads share this ring, a slot's words may be recycled before their owner looks -- else
   // into the slot's, which jb_wait / jb_poll check
   const double tt4 = timing ? now() : 0;
-  JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, down));
-  JB_HIP(ctx, hipEventRecord(s.done, down));
+  static const bool own_stream_downloads = getenv("JPEGBLK_DEV_DOWN") && getenv("JPEGBLK_DEV_DOWN")[0] == '0';  // A/B: the submission's own stream
+  if (dst_device || own_stream_downloads) {
+    if (!dst_device) {
+      if (rgb_stride == dev_stride)
+        JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, up));
+      else
+        JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
+                                     (size_t)desc->height, hipMemcpyDeviceToHost, up));
+    }
+    // (device output: the pixels stay on the device; only the status words come back)
+    JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, up));
+    JB_HIP(ctx, hipEventRecord(s.done, up));
+  } else {
+    // the download thread issues the copies once the kernels have finished (jb_ctx::dl_*)
+    JB_HIP(ctx, hipEventRecord(s.computed, up));
+    DlItem it;
+    it.slot = &s;
+    it.dst = rgb, it.src = s.d_rgb, it.bytes = rgb_total;
+    it.rows = 0, it.dst_pitch = it.src_pitch = it.row_bytes = 0;
+    if (rgb_stride != dev_stride)
+      it.rows = (size_t)desc->height, it.dst_pitch = (size_t)rgb_stride, it.src_pitch = (size_t)dev_stride, it.row_bytes = (size_t)desc->width * 3;
+    it.status_dst = status_out ? (void *)status_out : (void *)s.h_status;
+    it.status_src = s.d_status;
+    it.status_bytes = 4 * (size_t)n_images;
+    rc = dl_enqueue(ctx, it);
+    if (rc) return rc;
+  }
   if (timing)
     fprintf(stderr, "submit (device entropy): pack %.3f ms, upload + launches issued %.3f ms, entropy kernels done after %.3f ms more, pixel kernel + download call %.3f ms\n",
             (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, (tt4 - tt3) * 1e3);
@@ -831,7 +961,8 @@ int jb_wait(jb_ctx *ctx, int ticket) {
     Slot &s = ctx->slots[i];
     if (s.ticket == ticket) {
       if (s.busy) {
-        JB_HIP(ctx, hipEventSynchronize(s.done));
+        const int rc = slot_finish(ctx, s);
+        if (rc) return rc;
         s.busy = false;
       }
       return check_status(ctx, s);
@@ -847,6 +978,7 @@ int jb_poll(jb_ctx *ctx, int ticket) {
     Slot &s = ctx->slots[i];
     if (s.ticket == ticket) {
       if (!s.busy) return JB_OK;
+      if (s.dl_pending.load(std::memory_order_acquire)) return JB_PENDING;
       hipError_t e = hipEventQuery(s.done);
       if (e == hipErrorNotReady) return JB_PENDING;
       if (e != hipSuccess) return fail(ctx, JB_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(e));
@@ -924,14 +1056,12 @@ int jb_write_bmp(const char *path, const uint8_t *rgb, int32_t width, int32_t he
 // ring's own synchronisation on reuse (jb_submit) then returns at once.
 void *jb_wait_begin_(jb_ctx *ctx, int ticket) {
   for (int i = 0; i < ctx->n_slots; i++)
-    if (ctx->slots[i].ticket == ticket) return ctx->slots[i].busy ? (void *)ctx->slots[i].done : nullptr;
+    if (ctx->slots[i].ticket == ticket) return ctx->slots[i].busy ? (void *)&ctx->slots[i] : nullptr;
   return nullptr;  // the slot has been reused: that submission completed long ago
 }
-int jb_wait_block_(jb_ctx *ctx, void *event) {
+int jb_wait_block_(jb_ctx *ctx, void *slot) {
   DeviceGuard guard(ctx->device);
-  hipError_t e = hipEventSynchronize((hipEvent_t)event);
-  if (e != hipSuccess) return fail(nullptr, JB_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
-  return JB_OK;
+  return slot_finish(ctx, *(Slot *)slot);
 }
 
 // Bind the calling host thread to the CPUs of the NUMA node closest to `device` (intersected with

@@ -54,6 +54,7 @@ struct Frame {
   uint16_t qtabs[4][64];
   bool qset[4] = {false, false, false, false};
   HuffTable dc[4], ac[4];
+  int ncomp = 3;                  // 1: a single-component frame (only jb_huff_prepare_ asks for those: allow_gray)
   int comp_id[3] = {0, 0, 0};
   int dc_id[3] = {0, 0, 0}, ac_id[3] = {0, 0, 0};
   int restart_interval = 0;
@@ -61,7 +62,7 @@ struct Frame {
   size_t scan_len = 0;            // bytes up to the end of the buffer
 };
 
-int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
+int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e, bool allow_gray = false) {
   if (!d || n < 4 || d[0] != 0xff || d[1] != 0xd8) return set_err(e, JB_ERR_FORMAT, "not a JPEG file (no SOI)");
   size_t pos = 2;
   memset(fr.qtabs, 0, sizeof fr.qtabs);
@@ -99,6 +100,22 @@ int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
       if (s[0] != 8) return set_err(e, JB_ERR_UNSUPPORTED, "only 8-bit precision is supported");
       fr.desc.height = (s[1] << 8) | s[2];
       fr.desc.width = (s[3] << 8) | s[4];
+      if (s[5] == 1 && allow_gray) {
+        // one component (rejected by the reference, jpeg.cpp:83-87; the general front end delivers it as a 4:4:4 frame
+        // whose Cb and Cr blocks are zero, jb_frontend_ext.cpp parse_sof): its sampling factors are irrelevant
+        if (sl < 6 + 3) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
+        const int h = s[7] >> 4, v = s[7] & 15, tq = s[8];
+        if (tq > 3) return set_err(e, JB_ERR_QTAB, "quantisation table id > 3");
+        if (h < 1 || h > 4 || v < 1 || v > 4) return set_err(e, JB_ERR_SAMPLING, "bad sampling factor");
+        fr.ncomp = 1;
+        fr.comp_id[0] = s[6];
+        fr.desc.hs = fr.desc.vs = 1;
+        fr.desc.qtab_id[0] = fr.desc.qtab_id[1] = fr.desc.qtab_id[2] = tq;
+        fr.desc.reserved = 0;
+        if (fr.desc.width < 1 || fr.desc.height < 1) return set_err(e, JB_ERR_GEOMETRY, "empty image");
+        fr.have_sof = true;
+        continue;
+      }
       if (s[5] != 3) return set_err(e, JB_ERR_UNSUPPORTED, "only 3 components are supported");
       if (sl < 6 + 9) return set_err(e, JB_ERR_FORMAT, "bad SOF segment");
       for (int c = 0; c < 3; c++) {
@@ -147,6 +164,21 @@ int parse_headers(const uint8_t *d, size_t n, Frame &fr, Err &e) {
       fr.restart_interval = (s[0] << 8) | s[1];
     } else if (m == 0xda) {  // SOS, reference jpeg.cpp:233-287
       if (!fr.have_sof) return set_err(e, JB_ERR_FORMAT, "SOS before SOF");
+      if (fr.ncomp == 1) {
+        if (sl < 1 || s[0] != 1) return set_err(e, JB_ERR_FORMAT, "bad number of scan components");
+        if (sl != 1 + 2 + 3) return set_err(e, JB_ERR_FORMAT, "bad SOS length");
+        if (s[1] != fr.comp_id[0]) return set_err(e, JB_ERR_FORMAT, "scan component not in the frame");
+        fr.dc_id[0] = fr.dc_id[1] = fr.dc_id[2] = s[2] >> 4;
+        fr.ac_id[0] = fr.ac_id[1] = fr.ac_id[2] = s[2] & 15;
+        if (fr.dc_id[0] > 3 || fr.ac_id[0] > 3) return set_err(e, JB_ERR_FORMAT, "bad Huffman table id in SOS");
+        if (s[3] != 0 || s[4] != 63 || s[5] != 0) return set_err(e, JB_ERR_UNSUPPORTED, "a sequential scan of all 64 coefficients only");
+        if (!fr.qset[fr.desc.qtab_id[0]]) return set_err(e, JB_ERR_QTAB, "quantisation table not found");
+        if (!fr.dc[fr.dc_id[0]].set) return set_err(e, JB_ERR_FORMAT, "Huffman DC table not found");
+        if (!fr.ac[fr.ac_id[0]].set) return set_err(e, JB_ERR_FORMAT, "Huffman AC table not found");
+        fr.scan = d + pos;
+        fr.scan_len = n - pos;
+        return JB_OK;
+      }
       if (sl < 1 || s[0] != 3) return set_err(e, JB_ERR_UNSUPPORTED, "only 3-component scans are supported");
       if (sl != 1 + 6 + 3) return set_err(e, JB_ERR_FORMAT, "bad SOS length");
       for (int c = 0; c < 3; c++) {
@@ -269,7 +301,7 @@ bool jb_huff_fill_table_(const uint8_t counts[17], const uint8_t *symbols, bool 
 int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err) {
   Frame *fr = new Frame();
   Err e;
-  int rc = parse_headers(jpeg, jpeg_bytes, *fr, e);
+  int rc = parse_headers(jpeg, jpeg_bytes, *fr, e, true);
   auto done = [&](int code, const char *msg) {
     if (err) *err = msg ? msg : e.msg;
     delete fr;
@@ -286,7 +318,7 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   // the tables in use: a frame's three components name at most three tables of each kind (reference
   // jpeg.cpp:148-196 reads up to four ids of each kind); AC tables first, then DC
   int ac_ids[3] = {-1, -1, -1}, dc_ids[3] = {-1, -1, -1}, ac_slot[3], dc_slot[3], n_ac = 0, n_dc = 0;
-  for (int c = 0; c < 3; c++) {
+  for (int c = 0; c < fr->ncomp; c++) {
     for (int kind = 0; kind < 2; kind++) {
       int *ids = kind ? ac_ids : dc_ids, &n = kind ? n_ac : n_dc;
       const int id = kind ? fr->ac_id[c] : fr->dc_id[c];
@@ -309,8 +341,9 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
         return done(JB_ERR_UNSUPPORTED, "Huffman tables with more long codes than the device decoder's tables hold: host decoder");
     }
   }
+  // a single-component frame: one block per MCU in the scan, delivered as the Y block of a 4:4:4 MCU (Cb, Cr stay zero)
   const uint32_t ny = (uint32_t)(fr->desc.hs * fr->desc.vs);
-  job->img.nb = ny + 2;
+  job->img.nb = fr->ncomp == 1 ? 1u : ny + 2;
   job->img.lut_ac = job->img.lut_dc = job->img.lut_comp = 0;
   for (uint32_t b = 0; b < job->img.nb; b++) {
     const uint32_t c = b < ny ? 0u : b - ny + 1u;
@@ -333,7 +366,7 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   job->img.ri = (uint32_t)(ri > 0 ? ri : n_mcus);
   job->img.n_mcus = (uint32_t)n_mcus;
   job->img.coef_off = 0;
-  job->img.blk_bytes = 128;
+  job->img.blk_bytes = fr->ncomp == 1 ? 384u : 128u;
   job->img.wg0 = 0;
   if ((uint64_t)n_mcus * job->img.nb >= (1u << 24)) return done(JB_ERR_UNSUPPORTED, "more blocks than the device decoder's 24-bit block index holds: host decoder");
   job->img.n_blocks = (uint32_t)(n_mcus * job->img.nb);

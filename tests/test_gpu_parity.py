@@ -86,6 +86,62 @@ def test_decode_file_progressive_and_grayscale(jb, big_ctx, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_sixteen_bit_quant_entries_vs_oracle(jb, big_ctx, oracle, hs, vs):
+    """Quantisation entries of 256..65535 (Pq = 1 tables) through the fused kernel's 24-bit multiply, every layout,
+    Cb and Cr on different tables (the MIXQ instantiation) and on one: bit-exact against the oracle's int32
+    multiply.  PARITY WITH THE REFERENCE IS UNPINNED HERE: it keeps only the low byte of such entries
+    (jpeg.cpp:216), so there is no reference behaviour to match; the products are kept inside the range where its
+    float -> int conversions are defined (|coefficient x entry| <= 65535 per term)."""
+    from jpeg_decoder_amd import synth
+    from oracle.pyoracle import make_desc as odesc
+    rng = np.random.default_rng(16)
+    q = np.zeros((4, 64), np.uint16)
+    q[0] = rng.integers(256, 4000, 64)
+    q[1] = rng.integers(256, 65536, 64)
+    q[2] = 65535
+    q[3] = rng.integers(1, 65536, 64)
+    q[:, 0] = (300, 65535, 256, 1000)
+    for i, (w, h) in enumerate([(8, 8), (333, 211), (640, 360)]):
+        for qid in [(0, 1, 2), (3, 3, 3), (1, 2, 2)]:
+            n = oracle.geometry(odesc(w, h, hs, vs, qid)).n_coded_blocks
+            coef = np.zeros((n, 64), np.int16)
+            mask = rng.random((n, 64)) < 0.2
+            coef[mask] = rng.integers(-8, 9, int(mask.sum()))
+            big = q[list(qid)].max(0) > 8000                    # positions where a table in use has a large entry:
+            coef[:, big] = np.clip(coef[:, big], -1, 1)         # every term stays below 2^16
+            got = big_ctx.blocks_to_rgb(jb.make_desc(w, h, hs, vs, qid), coef, q)
+            want = oracle.blocks_to_rgb(odesc(w, h, hs, vs, qid), coef, q, nthreads=4)
+            assert np.array_equal(got, want), (w, h, hs, vs, qid)
+            assert got.min() < 40 and got.max() > 215   # the large entries do reach the pixels
+
+
+def test_grayscale_file_matches_the_oracle_on_its_blocks(jb, big_ctx, oracle, tmp_path):
+    """A single-component frame (rejected by the reference, jpeg.cpp:83-87) through decode(path): the pixels equal
+    the oracle's pixel path on the blocks the front end delivers (Y blocks of a 4:4:4 frame, Cb = Cr = 0), for
+    baseline and progressive encodings, with the entropy stage on the host and on the device."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from oracle.pyoracle import make_desc as odesc
+    rng = np.random.default_rng(3)
+    g = np.clip(np.cumsum(rng.normal(0, 6, (431, 613)), axis=1) + 120, 0, 255).astype(np.uint8)
+    for kw in ({}, {"progressive": True}, {"restart_marker_blocks": 9}):
+        p = tmp_path / "g.jpg"
+        Image.fromarray(g).save(p, "JPEG", quality=91, **kw)
+        desc, q, coef = jb.entropy_decode(p.read_bytes())
+        want = oracle.blocks_to_rgb(odesc(613, 431, desc.hs, desc.vs, list(desc.qtab_id)), coef, q)
+        for knob in ("0", "2"):
+            os.environ["JPEGBLK_GPU_HUFFMAN"] = knob
+            try:
+                before = big_ctx.device_entropy_images
+                got = big_ctx.decode_file(str(p))
+                took = big_ctx.device_entropy_images - before
+            finally:
+                os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+            assert np.array_equal(got, want), (kw, knob)
+            assert took == (1 if knob == "2" and "progressive" not in kw else 0), (kw, knob)
+
+
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 1), (1, 2), (2, 2)])
 def test_random_blocks_vs_oracle_ragged_sizes(jb, big_ctx, oracle, hs, vs):
     from jpeg_decoder_amd import synth
     from oracle.pyoracle import make_desc as odesc

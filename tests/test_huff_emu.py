@@ -62,6 +62,54 @@ def test_writer_streams_every_layout(emu, tmp_path, hs, vs):
         assert r.returncode == 0, r.stdout + r.stderr
 
 
+def three_table_variant(data):
+    """The same stream with the Cr component on Huffman tables of its own (ids 2: copies of the Cb tables, ids 1):
+    a frame may name three tables of each kind (reference jpeg.cpp:148-196 reads ids up to 3)."""
+    d = bytearray(data)
+    sos = d.index(b"\xff\xda")
+    tabs, i = {}, 2
+    while i < sos:  # the DHT segments in front of the scan
+        assert d[i] == 0xff
+        m, ln = d[i + 1], (d[i + 2] << 8) | d[i + 3]
+        if m == 0xc4:
+            j = i + 4
+            while j < i + 2 + ln:
+                n = sum(d[j + 1:j + 17])
+                tabs[d[j]] = bytes(d[j + 1:j + 17 + n])
+                j += 17 + n
+        i += 2 + ln
+    extra = b"".join(bytes([tc_th + 1]) + tabs[tc_th] for tc_th in (0x01, 0x11))
+    assert d[sos + 4] == 3 and d[sos + 10] == 0x11   # Ns = 3; the third component's selectors
+    d[sos + 10] = 0x22
+    return bytes(d[:sos]) + b"\xff\xc4" + (2 + len(extra)).to_bytes(2, "big") + extra + bytes(d[sos:])
+
+
+def test_grayscale_and_three_tables_per_kind(emu, tmp_path):
+    """Single-component baseline frames (one block per MCU in the scan, delivered as the Y blocks of a 4:4:4 frame),
+    with and without restart intervals, Annex-K and optimised tables; and a frame whose three components name three
+    different tables of each kind."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    from jpeg_decoder_amd import synth
+    rng = np.random.default_rng(4)
+    g = np.clip(np.cumsum(rng.normal(0, 5, (397, 531)), axis=1) + 128, 0, 255).astype(np.uint8)
+    paths = []
+    for name, kw in (("gray", {}), ("gray_dri", {"restart_marker_blocks": 5}), ("gray_opt", {"optimize": True})):
+        b = io.BytesIO()
+        Image.fromarray(g).save(b, "JPEG", quality=88, **kw)
+        (tmp_path / (name + ".jpg")).write_bytes(b.getvalue())
+        paths.append(str(tmp_path / (name + ".jpg")))
+    for (hs, vs) in ((1, 1), (2, 2)):
+        coef, q = synth.synth_blocks(333, 211, hs, vs, 5)
+        p = tmp_path / f"three_{hs}{vs}.jpg"
+        p.write_bytes(three_table_variant(synth.encode_jpeg(coef, 333, 211, hs, vs, q)))
+        paths.append(str(p))
+    for chunk in (128, 64):
+        r = run(emu, paths, chunk)
+        assert r.returncode == 0 and "not taken" not in r.stdout, r.stdout + r.stderr
+
+
 def test_dense_random_data_needs_the_second_launch_or_flags(emu, tmp_path):
     """Uniform random coefficients in the full baseline alphabet (16-bit codes with 10 magnitude bits, hardly any EOB
     to fall into step at): the second-level tables run for most symbols, and lanes rarely meet their previous paths.

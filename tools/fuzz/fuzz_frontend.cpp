@@ -124,10 +124,34 @@ static void mutate(std::vector<uint8_t> &d) {
 static void prepare_once(const std::vector<uint8_t> &in) {
   static JbHuffJob job;
   if (jb_huff_prepare_(in.data(), in.size(), &job, nullptr) != JB_OK) return;
-  bool bad = job.starts.size() != (size_t)job.img.n_int + 1 || job.scan.size() < job.scan_len + 64 || job.starts.back() != job.scan_len ||
-             (uint64_t)job.img.n_int * job.img.ri < job.img.n_mcus || job.img.ny < 1 || job.img.ny > 4;
-  for (size_t i = 1; !bad && i < job.starts.size(); i++) bad = job.starts[i] < job.starts[i - 1];
-  for (int c = 0; !bad && c < 3; c++) bad = job.img.dc_slot[c] > 1 || job.img.ac_slot[c] > 1;
+  const JbHuffImage &im = job.img;
+  bool bad = job.starts.size() != (size_t)im.n_int + 1 || job.scan.size() < job.scan_len + 64 || job.starts.back() != job.scan_len ||
+             (uint64_t)im.n_int * im.ri < im.n_mcus || !(im.nb == 1 || im.nb == 3 || im.nb == 4 || im.nb == 6) ||
+             (uint64_t)im.n_mcus * im.nb != im.n_blocks || im.n_blocks >= (1u << 24) || im.n_tabs < 2 || im.n_tabs > kJbMaxTabs ||
+             im.n_tabs != job.n_tabs || !(im.chunk_bytes == 64 || im.chunk_bytes == 128) || !(im.blk_bytes == 128 || im.blk_bytes == 384);
+  uint64_t chunks = 0;
+  bool multi = false;
+  for (size_t i = 1; !bad && i < job.starts.size(); i++) {
+    bad = job.starts[i] < job.starts[i - 1];
+    const uint32_t k = jb_chunks_of_(job.starts[i] - job.starts[i - 1], im.chunk_bytes);
+    chunks += k;
+    multi |= k > 1;
+  }
+  bad = bad || chunks != im.n_chunks || (multi ? 1u : 0u) != im.needs_sync;
+  // block-in-MCU -> table / component: indices the kernels use without a check
+  for (uint32_t blk = 0; !bad && blk < im.nb; blk++)
+    bad = ((im.lut_ac >> (4 * blk)) & 15u) >= im.n_tabs || ((im.lut_dc >> (4 * blk)) & 15u) >= im.n_tabs || ((im.lut_comp >> (4 * blk)) & 15u) > 2;
+  // table entries: nothing, a second-level table that exists, or a symbol of at most 27 bits
+  for (uint32_t t = 0; !bad && t < im.n_tabs; t++)
+    for (uint32_t i = 0; !bad && i < kJbT1Entries; i++) {
+      const uint16_t e = job.tables.t1[t][i];
+      bad = e != 0 && !(e >= 1 && e <= kJbT2Tables) && !(e >= 512 && (e & 31) >= 1 && (e & 31) <= 27 && ((e >> 5) & 15) <= 11);
+    }
+  for (uint32_t t = 0; !bad && t < kJbT2Tables; t++)
+    for (uint32_t i = 0; !bad && i < kJbT2Entries; i++) {
+      const uint16_t e = job.tables.t2[t][i];
+      bad = e != 0 && !(e >= 512 && (e & 31) >= 1 && (e & 31) <= 27 && ((e >> 5) & 15) <= 11);
+    }
   if (bad) {
     fprintf(stderr, "jb_huff_prepare_ produced an inconsistent job\n");
     abort();
