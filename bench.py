@@ -27,8 +27,9 @@ Prints ONE JSON line on rank 0:  metric = Mpixels/s decoded (whole job), plus
                Cache), HIP events around every launch, median of >= 200; plus the per-GPU shares
                of the batch configs and the reference's bundled-image size;
   end_to_end   decode(path) over batches of synthetic JPEG FILES (written by the build's own baseline
-               writer): BASELINE.json configs 4 and 5 weak-scaled like the headline -- every rank
-               decodes one GPU's share at 8 GPUs (128 x 1920x1080 4:4:4, 32 x 8192x8192 4:2:0)
+               writer): BASELINE.json configs 4 and 5 in two forms -- weak: every rank decodes one
+               GPU's share at 8 GPUs (128 x 1920x1080 4:4:4, 32 x 8192x8192 4:2:0); strong: the
+               batch as stated (1,024 / 256 files) dealt over the ranks by image index --
                through jb_batch_decoder: parse + byte de-stuffing on the host threads, Huffman
                decoding + IDCT + colour on the device, pixels into pinned host memory (PCIe-
                inclusive, so never `value`); images/s = all ranks' images / the slowest rank's wall;
@@ -143,97 +144,133 @@ def fan_out(n_gpus, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-# (key, workload, files per GPU, restart interval in MCU rows, what it is): BASELINE.json's batch
-# configurations as files on disk, one GPU's share at 8 GPUs per rank
+# (key, workload, files in the whole batch as BASELINE.json states it, files per GPU when weak-scaled = the share at 8 GPUs,
+#  distinct files, restart interval in MCU rows, what it is)
 E2E_CONFIGS = [
-    ("config4_files_1080p_444", "1920x1080-444", 128, 0, "BASELINE config 4: 1024 x 1920x1080 4:4:4 JPEG files over 8 GPUs = 128 per GPU"),
-    ("config5_files_8192_420", "8192x8192-420", 32, 0, "BASELINE config 5: 256 x 8192x8192 4:2:0 JPEG files over 8 GPUs = 32 per GPU"),
+    ("config4_files_1080p_444", "1920x1080-444", 1024, 128, 8, 0, "BASELINE config 4: 1024 x 1920x1080 4:4:4 JPEG files"),
+    ("config5_files_8192_420", "8192x8192-420", 256, 32, 4, 0, "BASELINE config 5: 256 x 8192x8192 4:2:0 JPEG files"),
 ]
+E2E_SUB_BATCH_BYTES = 8 << 30   # a rank's share is decoded in sub-batches whose pixels fit a pinned arena of this size
+
+
+def host_threads(world):
+    """Host threads of one rank: device-entropy batches need few (they parse, de-stuff and pack: 16 saturate the
+    link), host-entropy batches take every CPU the rank may use (the library clamps by the cgroup quota as well)."""
+    cpus = max(1, len(os.sched_getaffinity(0)) // world)
+    return max(2, min(16, cpus)), max(2, min(64, cpus))
 
 
 def end_to_end(jb, np, torch, dist, dev_index, reduce_device, rank, world, tmpdir):
-    """decode(path) over batches of files, every rank its own share; -> dict (identical on all ranks)."""
+    """decode(path) over batches of files; -> dict (identical on all ranks).  Two forms per configuration:
+    weak   every rank decodes one GPU's share at 8 GPUs (128 / 32 files): the per-GPU rate as N grows;
+    strong the batch BASELINE.json states (1,024 / 256 files) is dealt over the ranks by image index
+           (jpeg_decoder_amd.shard.shard_images): at N = 8 both forms are the same batch."""
     from jpeg_decoder_amd import synth
-    from jpeg_decoder_amd.shard import job_throughput
-    threads = max(2, min(16, len(os.sched_getaffinity(0)) // world))  # (the library caps it by the cgroup CPU quota as well)
+    from jpeg_decoder_amd.shard import job_throughput, shard_images
+    thr_dev, thr_host = host_threads(world)
     out = {"what": "jb_batch_decoder over JPEG files on local disk (page cache): parse + de-stuffing on the host threads, "
-                   "entropy decoding + IDCT + colour on the device, pixels into a pinned host arena; weak-scaled: files per GPU fixed",
-           "host_threads_per_gpu": threads, "files": "synthetic blocks through tools/jpegwriter (Annex-K tables, quality-75 tables), 2 distinct per size, the rest MCU rotations",
+                   "entropy decoding + IDCT + colour on the device, pixels into a pinned host arena; images/s = all ranks' images / the slowest rank's wall",
+           "host_cpus": os.cpu_count(), "cpu_affinity": len(os.sched_getaffinity(0)),
+           "host_threads_per_gpu": {"entropy_on_device": thr_dev, "entropy_on_host": thr_host},
+           "files": "synthetic blocks through tools/jpegwriter (Annex-K Huffman tables, quality-75 quantisation), distinct per size as listed, the rest repeats",
+           "checked_against": "the single-image decode(path) with the entropy stage on the HOST decoder (JPEGBLK_GPU_HUFFMAN=0), "
+                              "itself pinned to the reference's coefficient dumps and the oracle by tests/: one image of every distinct file per rank and form",
            "runs": {}}
-    for key, wl, per_gpu, ri_rows, what in E2E_CONFIGS:
+    for key, wl, total, per_gpu, distinct, ri_rows, what in E2E_CONFIGS:
         w, h, hs, vs = parse_workload(wl)
         coef, q = synth.synth_blocks(w, h, hs, vs, image_index=7)
         bpm = hs * vs + 2
         mcus_x = (w + 8 * hs - 1) // (8 * hs)
         paths = []
-        for i in range(2):
+        for i in range(distinct):
             path = os.path.join(tmpdir, f"{key}_{i}.jpg")
             with open(path, "wb") as f:
                 f.write(synth.encode_jpeg(np.roll(coef, i * 4099 * bpm, axis=0), w, h, hs, vs, q, restart_interval=ri_rows * mcus_x))
             paths.append(path)
         del coef
-        files = [paths[i % 2] for i in range(per_gpu)]
+        os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
         with jb.Context(dev_index) as one:
             want = [one.decode_file(p) for p in paths]
-        g = jb.geometry_of(jb.make_desc(w, h, hs, vs))
-        res = {"what": what, "workload": wl, "files_per_gpu": per_gpu, "file_bytes": os.path.getsize(paths[0])}
-        modes = [("device", None)] + ([("host", "0")] if world == 1 else [])
-        for label, knob in modes:
-            if knob is None:
-                os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
-            else:
-                os.environ["JPEGBLK_GPU_HUFFMAN"] = knob
-            arena = per_gpu * ((g.rgb_bytes + 255) // 256 * 256)
-            bad = []
-
-            def check(i, view):
-                if i < 4 and not np.array_equal(view, want[i % 2]):
-                    bad.append(i)
-
-            with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes, arena_bytes=arena) as dec:
-                dec.run(files[:threads], keep_pixels=False)
-                walls = []
-                for k in range(3):
-                    if dist is not None:
-                        dist.barrier()
-                    _, st, tm = dec.run(files, keep_pixels=False, on_image=check if k == 0 else None)
-                    if any(x != 0 for x in st) or bad:
-                        raise RuntimeError(f"end_to_end {key}: statuses {sorted(set(st))}, images that differ from the single-image decode: {bad}")
-                    n_all, wall = job_throughput(dist, reduce_device, per_gpu, tm["wall_s"])
-                    walls.append(wall)
-                on_device = dec.device_entropy_images > 0
-            best = min(walls)
-            res[f"entropy_on_{label}"] = {"images_per_s": round(n_all / best, 1), "mpix_s": round(n_all * w * h / best / 1e6, 1),
-                                           "wall_s": round(best, 4), "walls": [round(x, 4) for x in walls], "images": int(n_all),
-                                           "entropy_stage_ran_on_device": bool(on_device), "pixels_checked_per_rank": 4}
         os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
-        # the same batch with the decoded images left in device memory (jb_batch_decoder_set_device_output):
-        # nothing is downloaded, so this is what the pipeline does when the link is not in the way
+        g = jb.geometry_of(jb.make_desc(w, h, hs, vs))
         per = (g.rgb_bytes + 255) // 256 * 256
-        region = torch.empty(per_gpu * per, dtype=torch.uint8, device=f"cuda:{dev_index}")
-        with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes) as dec:
-            dec.set_device_output(region.data_ptr(), region.numel())
-            dec.run_to_device(files[:threads])
-            walls = []
-            for k in range(3):
-                if dist is not None:
-                    dist.barrier()
-                ptrs, dims, st, tm = dec.run_to_device(files)
-                if any(x != 0 for x in st):
-                    raise RuntimeError(f"end_to_end {key} (device output): statuses {sorted(set(st))}")
-                if k == 0:
-                    for i in range(4):
-                        off = ptrs[i] - region.data_ptr()
-                        if not np.array_equal(region[off:off + g.rgb_bytes].cpu().numpy().reshape(want[i % 2].shape), want[i % 2]):
-                            raise RuntimeError(f"end_to_end {key} (device output): image {i} differs from the single-image decode")
-                n_all, wall = job_throughput(dist, reduce_device, per_gpu, tm["wall_s"])
-                walls.append(wall)
-        best = min(walls)
-        res["entropy_on_device_pixels_stay_in_hbm"] = {"images_per_s": round(n_all / best, 1), "mpix_s": round(n_all * w * h / best / 1e6, 1),
-                                                       "wall_s": round(best, 4), "walls": [round(x, 4) for x in walls], "images": int(n_all),
-                                                       "pixels_checked_per_rank": 4}
-        del region
-        torch.cuda.empty_cache()
+        res = {"what": what, "workload": wl, "batch_files": total, "files_per_gpu_weak": per_gpu, "distinct_files": distinct,
+               "file_bytes": os.path.getsize(paths[0])}
+        forms = [("weak", list(range(per_gpu)))]
+        mine = shard_images(total, rank, world)
+        forms.append(("strong", mine))
+        for form, idx in forms:
+            files = [paths[i % distinct] for i in idx]
+            n_mine = len(files)
+            sub = max(1, min(n_mine, E2E_SUB_BATCH_BYTES // per))   # files per run (one arena's worth)
+            fres = {"files_this_rank": n_mine, "files_per_run": sub}
+            modes = [("device", None, thr_dev)] + ([("host", "0", thr_host)] if world == 1 else [])
+            for label, knob, threads in modes:
+                if knob is None:
+                    os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+                else:
+                    os.environ["JPEGBLK_GPU_HUFFMAN"] = knob
+                bad, seen = [], set()
+
+                def check(i, view, base=0):
+                    k = idx[base + i] % distinct
+                    if k not in seen:
+                        seen.add(k)
+                        if not np.array_equal(view, want[k]):
+                            bad.append(base + i)
+
+                with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes, arena_bytes=sub * per) as dec:
+                    dec.run(files[:min(threads, sub)], keep_pixels=False)
+                    walls = []
+                    reps = 3 if form == "weak" or n_mine * per <= (16 << 30) else 1
+                    for k in range(reps):
+                        if dist is not None:
+                            dist.barrier()
+                        wall = 0.0
+                        for at in range(0, n_mine, sub):
+                            _, st, tm = dec.run(files[at:at + sub], keep_pixels=False,
+                                                on_image=(lambda i, v, base=at: check(i, v, base)) if k == 0 else None)
+                            if any(x != 0 for x in st) or bad:
+                                raise RuntimeError(f"end_to_end {key} {form}: statuses {sorted(set(st))}, images that differ from the host-entropy decode: {bad}")
+                            wall += tm["wall_s"]
+                        n_all, wall = job_throughput(dist, reduce_device, n_mine, wall)
+                        walls.append(wall)
+                    on_device = dec.device_entropy_images > 0
+                best, med = min(walls), sorted(walls)[len(walls) // 2]
+                fres[f"entropy_on_{label}"] = {"images_per_s": round(n_all / best, 1), "images_per_s_median": round(n_all / med, 1),
+                                               "mpix_s": round(n_all * w * h / best / 1e6, 1), "wall_s": round(best, 4),
+                                               "walls": [round(x, 4) for x in walls], "images": int(n_all), "host_threads": threads,
+                                               "entropy_stage_ran_on_device": bool(on_device), "distinct_files_checked_per_rank": len(seen)}
+            os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+            if form == "weak":
+                # the same share with the decoded images left in device memory (jb_batch_decoder_set_device_output):
+                # nothing is downloaded, so this is what the pipeline does when the link is not in the way
+                region = torch.empty(n_mine * per, dtype=torch.uint8, device=f"cuda:{dev_index}")
+                with jb.BatchDecoder(thr_dev, dev_index, g.coef_bytes, g.rgb_bytes) as dec:
+                    dec.set_device_output(region.data_ptr(), region.numel())
+                    dec.run_to_device(files[:thr_dev])
+                    walls = []
+                    for k in range(3):
+                        if dist is not None:
+                            dist.barrier()
+                        ptrs, dims, st, tm = dec.run_to_device(files)
+                        if any(x != 0 for x in st):
+                            raise RuntimeError(f"end_to_end {key} (device output): statuses {sorted(set(st))}")
+                        if k == 0:
+                            for i in range(min(distinct, n_mine)):
+                                off = ptrs[i] - region.data_ptr()
+                                if not np.array_equal(region[off:off + g.rgb_bytes].cpu().numpy().reshape(want[0].shape), want[idx[i] % distinct]):
+                                    raise RuntimeError(f"end_to_end {key} (device output): image {i} differs from the host-entropy decode")
+                        n_all, wall = job_throughput(dist, reduce_device, n_mine, tm["wall_s"])
+                        walls.append(wall)
+                best, med = min(walls), sorted(walls)[len(walls) // 2]
+                fres["entropy_on_device_pixels_stay_in_hbm"] = {"images_per_s": round(n_all / best, 1), "images_per_s_median": round(n_all / med, 1),
+                                                                "mpix_s": round(n_all * w * h / best / 1e6, 1), "wall_s": round(best, 4),
+                                                                "walls": [round(x, 4) for x in walls], "images": int(n_all),
+                                                                "distinct_files_checked_per_rank": min(distinct, n_mine)}
+                del region
+                torch.cuda.empty_cache()
+            res[form] = fres
         out["runs"][key] = res
         for p_ in paths:
             os.remove(p_)
@@ -292,9 +329,10 @@ def main():
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         sys.exit(fan_out(args.gpus, sys.argv[1:]))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from jpeg_decoder_amd.shard import rank_from_env
+    # rehearsal knob (never set by the driver): every rank on device 0 of a one-GPU box
+    single_device = os.environ.get("JB_BENCH_SINGLE_DEVICE") == "1"
+    world, rank, local_rank = rank_from_env(os.environ, single_device)
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs "
               f"(launch with --nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` without a launcher)",
@@ -309,9 +347,6 @@ def main():
     dist = None
     # rehearsal knobs (never set by the driver): run N ranks on a one-GPU box
     backend = os.environ.get("JB_BENCH_BACKEND", "nccl")  # "nccl" = RCCL on ROCm
-    single_device = os.environ.get("JB_BENCH_SINGLE_DEVICE") == "1"
-    if single_device:
-        local_rank = 0
     if jb.lib().jb_device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: " + jb.lib().jb_last_error(None).decode())
     if not single_device and jb.lib().jb_device_count() < world:

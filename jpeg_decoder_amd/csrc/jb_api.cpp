@@ -37,11 +37,14 @@ namespace {
 // run their kernels one after the other.  Measured with 16 submitting threads: 1,024 1080p files
 // 2,838 -> 3,211 images/s (host entropy), 4,807 -> 5,428 (device entropy), 128 files 2,398 -> 3,344,
 // with 16 queues instead of 4.  So the library asks for 16 when it is loaded -- only if the variable
-// is not set already, and only effective if the process has not initialised HIP yet
-// (JPEGBLK_HW_QUEUES=0 leaves the runtime's default alone, =N asks for N).
+// is not set already, and only effective if the process has not initialised HIP yet: an application
+// that initialises HIP first (torch, say) sets GPU_MAX_HW_QUEUES=16 itself, or loads this library
+// first.  The setting is process-wide (every HIP user of the process gets 16 queues);
+// JPEGBLK_HW_QUEUES=0 leaves the runtime's default alone, =N asks for N (include/jpegblk.h says the same).
 __attribute__((constructor)) void jb_ask_for_hw_queues() {
   const char *k = getenv("JPEGBLK_HW_QUEUES");
   if (k && k[0] == '0' && k[1] == 0) return;
+  if (getenv("GPU_MAX_HW_QUEUES")) return;  // the application's own choice stands
   setenv("GPU_MAX_HW_QUEUES", (k && k[0]) ? k : "16", 0);
 }
 
@@ -816,20 +819,14 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
   // -- many threads share this ring, a slot's words may be recycled before their owner looks -- else
   // into the slot's, which jb_wait / jb_poll check
   const double tt4 = timing ? now() : 0;
-  static const bool own_stream_downloads = getenv("JPEGBLK_DEV_DOWN") && getenv("JPEGBLK_DEV_DOWN")[0] == '0';  // A/B: the submission's own stream
-  if (dst_device || own_stream_downloads) {
-    if (!dst_device) {
-      if (rgb_stride == dev_stride)
-        JB_HIP(ctx, hipMemcpyAsync(rgb, s.d_rgb, rgb_total, hipMemcpyDeviceToHost, up));
-      else
-        JB_HIP(ctx, hipMemcpy2DAsync(rgb, (size_t)rgb_stride, s.d_rgb, (size_t)dev_stride, (size_t)desc->width * 3,
-                                     (size_t)desc->height, hipMemcpyDeviceToHost, up));
-    }
-    // (device output: the pixels stay on the device; only the status words come back)
+  if (dst_device) {
+    // the pixels stay on the device; only the status words come back
     JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, up));
     JB_HIP(ctx, hipEventRecord(s.done, up));
   } else {
-    // the download thread issues the copies once the kernels have finished (jb_ctx::dl_*)
+    // the download thread issues the copies once the kernels have finished (jb_ctx::dl_*; against the copies on the
+    // submission's own stream: 1,024 1080p files 6,467-7,008 -> 7,742-7,815 images/s, 128 files 4,257-4,318 ->
+    // 5,767-6,567, 64 8192x8192 files 227-238 -> 262: profiles/r03/ab_download_thread.txt)
     JB_HIP(ctx, hipEventRecord(s.computed, up));
     DlItem it;
     it.slot = &s;

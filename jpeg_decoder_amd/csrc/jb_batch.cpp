@@ -484,6 +484,11 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       if (dev_entropy) {
         job.reset(new JbHuffJob());
         eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_intervals);
+        // the frame this pass reads must be the frame pass 1 sized the group for (a file that changed in between):
+        // else the host path below settles the image, with its own capacity checks
+        if (eligible && (job->desc.width != p.desc.width || job->desc.height != p.desc.height || job->desc.hs != p.desc.hs ||
+                         job->desc.vs != p.desc.vs || memcmp(job->desc.qtab_id, p.desc.qtab_id, sizeof p.desc.qtab_id) != 0))
+          eligible = false;
       }
       if (n == 0) on_device = eligible;
       else if (eligible != on_device) break;  // the next group starts with this image
@@ -594,7 +599,12 @@ struct jb_batch_decoder {
   jb_ctx *ctx = nullptr;      // the one context all host threads of this device submit to
   size_t ctx_coef = 0, ctx_rgb = 0;
   int ctx_ring = 0;
-  int slots() const { return lane_slots(arena->base && arena->on_device); }
+  // (never more submissions in flight than the context's ring of 64 slots holds: a thread that found the ring full
+  // would wait for the oldest submission while holding the lock every other thread submits under)
+  int slots() const {
+    const int want = lane_slots(arena->base && arena->on_device), fit = lanes.empty() ? want : 64 / (int)lanes.size();
+    return want < fit ? want : fit < 1 ? 1 : fit;
+  }
   // multi-device decoder (jb_batch_decoder_create_multi): one single-device decoder per listed
   // device; this object then only deals the files out and owns the shared arena
   std::vector<jb_batch_decoder *> parts;
@@ -644,7 +654,7 @@ namespace {
 
 int clamp_threads(int n_threads) {
   if (n_threads < 1) n_threads = 1;
-  if (n_threads > 256) n_threads = 256;
+  if (n_threads > 64) n_threads = 64;  // one ring slot each at least (64 host threads decode 30 Gpixel/s: far beyond the link)
   // no more entropy threads than CPUs this process may use (JPEGBLK_OVERSUBSCRIBE=1 lifts that)
   const char *over = getenv("JPEGBLK_OVERSUBSCRIBE");
   if (!(over && over[0] == '1') && n_threads > available_cpus()) n_threads = available_cpus();

@@ -26,3 +26,16 @@ def job_throughput(dist, device, pixels_local, elapsed_local):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(p, op=dist.ReduceOp.SUM)
     return float(p.item()), float(t.item())
+
+
+def rank_from_env(env, single_device=False):
+    """(world, rank, device index) of this process from the launcher's environment
+    (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK): one process per GPU, rank r of a
+    node drives device LOCAL_RANK.  single_device: every rank on device 0 (rehearsing N ranks on a
+    one-GPU box).  Used by bench.py and tools/e2e_bench.py; unit-tested on the CPU."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local = int(env.get("LOCAL_RANK", "0"))
+    if world < 1 or not (0 <= rank < world) or local < 0:
+        raise ValueError(f"inconsistent launcher environment: WORLD_SIZE={world} RANK={rank} LOCAL_RANK={local}")
+    return world, rank, (0 if single_device else local)

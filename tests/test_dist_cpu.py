@@ -92,3 +92,30 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
                            capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 2, (world, gpus, r.stdout, r.stderr)
         assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launcher_environment_to_device_index():
+    """One process per GPU: rank r of the node drives device LOCAL_RANK (bench.py, tools/e2e_bench.py); the
+    rehearsal knobs put every rank on device 0; an inconsistent environment is an error, not device 0."""
+    from jpeg_decoder_amd.shard import rank_from_env, shard_images
+    assert rank_from_env({}) == (1, 0, 0)
+    for world in (2, 4, 8):
+        seen = set()
+        for r in range(world):
+            w, rank, dev = rank_from_env({"WORLD_SIZE": str(world), "RANK": str(r), "LOCAL_RANK": str(r)})
+            assert (w, rank, dev) == (world, r, r)
+            seen.update(shard_images(1024, rank, w))
+            assert rank_from_env({"WORLD_SIZE": str(world), "RANK": str(r), "LOCAL_RANK": str(r)}, single_device=True) == (world, r, 0)
+        assert seen == set(range(1024))          # the strong-scaled batch: every file exactly once
+    for bad in ({"WORLD_SIZE": "2", "RANK": "2", "LOCAL_RANK": "0"}, {"WORLD_SIZE": "0"}, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "-1"}):
+        with pytest.raises(ValueError):
+            rank_from_env(bad)
+
+
+def test_bench_and_e2e_bench_take_the_device_from_the_same_helper():
+    """Both drivers map LOCAL_RANK -> device through jpeg_decoder_amd.shard.rank_from_env (no copy of the rule that
+    could drift), and hand that index to jb.Context / jb.BatchDecoder."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("bench.py", os.path.join("tools", "e2e_bench.py")):
+        text = open(os.path.join(root, rel)).read()
+        assert "rank_from_env(os.environ" in text and 'os.environ.get("LOCAL_RANK"' not in text, rel

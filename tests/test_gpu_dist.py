@@ -71,6 +71,24 @@ def test_bench_gpus_2_run_plainly_reports_two_ranks():
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
     # configs 4 and 5 end to end over files: every rank decodes its share, the line counts all of them
     runs = d["end_to_end"]["runs"]
-    assert runs["config4_files_1080p_444"]["entropy_on_device"]["images"] == 2 * 128
-    assert runs["config5_files_8192_420"]["entropy_on_device"]["images"] == 2 * 32
-    assert all(r["entropy_on_device"]["entropy_stage_ran_on_device"] and r["entropy_on_device"]["images_per_s"] > 0 for r in runs.values())
+    assert runs["config4_files_1080p_444"]["weak"]["entropy_on_device"]["images"] == 2 * 128
+    assert runs["config5_files_8192_420"]["weak"]["entropy_on_device"]["images"] == 2 * 32
+    # strong-scaled: the batch as BASELINE.json states it, dealt over the two ranks
+    assert runs["config4_files_1080p_444"]["strong"]["entropy_on_device"]["images"] == 1024
+    assert runs["config5_files_8192_420"]["strong"]["entropy_on_device"]["images"] == 256
+    for r in runs.values():
+        for form in ("weak", "strong"):
+            assert r[form]["entropy_on_device"]["entropy_stage_ran_on_device"] and r[form]["entropy_on_device"]["images_per_s"] > 0
+
+
+def test_bench_one_rank_over_rccl():
+    """The N > 1 code path with ONE rank: process group over RCCL (backend "nccl"), barriers and the reductions of
+    job_throughput on the GPU -- what a one-GPU box can run of what the driver's 8-GPU node runs."""
+    env = dict(os.environ, JB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                        "--precondition", "10", "--images-per-step", "2", "--no-cpu-baseline", "--no-configs", "--no-e2e"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1

@@ -140,8 +140,8 @@ def main():
                     "timed batch (tools/timeline.py reads that burst out of a rocprofv3 trace)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    device = 0 if os.environ.get("E2E_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    from jpeg_decoder_amd.shard import rank_from_env
+    world, rank, device = rank_from_env(os.environ, os.environ.get("E2E_SINGLE_DEVICE") == "1")
     dist = None
     if world > 1:
         import torch.distributed as dist
