@@ -38,6 +38,27 @@
  * calls exit() (the reference logs and exit(1)s, e.g. jpeg.cpp:71-72,85-86).
  * THREADING: a jb_ctx is bound to one device and its own HIP streams; calls on one ctx must be
  * serialised by the caller, different contexts may be used concurrently from different threads.
+ *
+ * ENVIRONMENT.  None of these is needed for normal use: they select a path for tests and A/B
+ * measurements, or adapt the host side to its machine.  Each is read ONCE PER OBJECT -- when a
+ * context (jb_ctx_create) or a batch decoder (jb_batch_decoder_create*, jb_decode_batch) is created
+ * -- and kept there (csrc/jb_knobs.h is the one place that reads them):
+ *   JPEGBLK_GPU_HUFFMAN    where the entropy stage runs: unset = batch decoders on the device for files
+ *                          of 16 chunks (2 KB of scan) or more, single images from 256 KB of scan on;
+ *                          0 = always the host threads (north_star's split); 1 = the device for every
+ *                          file of 16 chunks or more; 2 = the device for every file it takes
+ *   JPEGBLK_CHUNK_BYTES    64 | 128: scan bytes per lane of the device entropy decoder (default 128)
+ *   JPEGBLK_BYTE_STORE     1 = every pixel through byte stores (the second store implementation)
+ *   JPEGBLK_ROW_TILING     1 = the row-bound tiling for every image
+ *   JPEGBLK_GROUP_MB       MB of coefficients per group of small images on the host path (16; 0 = one image per submission)
+ *   JPEGBLK_DEV_GROUP_MB   MB of coefficients per group whose entropy stage runs on the device (96)
+ *   JPEGBLK_NUMA           0 = leave the host threads' CPU affinity alone, 1 = always bind them to the GPU's node
+ *   JPEGBLK_OVERSUBSCRIBE  1 = allow more host threads than CPUs the process may use
+ *   JPEGBLK_TIMING         1 | 2 = where one decode(bytes) / one device-entropy submission spends its time (stderr)
+ *   JPEGBLK_HW_QUEUES      read when the library is LOADED: hardware queues to ask the HIP runtime for
+ *                          (GPU_MAX_HW_QUEUES; default 16, 0 = the runtime's default).  Process-wide, and only
+ *                          effective before HIP initialises: an application that initialises HIP first sets
+ *                          GPU_MAX_HW_QUEUES=16 itself (batch decoders: +13 % host path, +13-40 % device path).
  */
 #ifndef JPEGBLK_H
 #define JPEGBLK_H
@@ -210,29 +231,27 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
                          uint16_t *qtabs /* 4*64 */, int16_t *coef, size_t coef_cap_bytes,
                          int n_threads);
 /* The entropy stage ON THE DEVICE (beyond the reference, whose decodeHuffman() -- jpeg.cpp:405-446 --
- * is serial host code): the host only parses the headers and removes the byte stuffing.  Files with
- * short restart intervals (DRI; e.g. the reference's images/img4.jpg): every interval is
- * Huffman-decoded by its own GPU lane (the DC predictors reset at each restart, jpeg.cpp:419-425, so
- * intervals are independent).  Files without DRI (the reference's other bundled images, most files
- * anywhere) and files with long intervals: the self-synchronising decoder -- one lane per 256-byte
- * chunk of every interval, a few passes in which the lanes fall into step with the true symbol
- * sequence, a prefix sum that gives every chunk its block index and DC predictors, and a writing
- * pass that verifies the chain of chunk states.  Both
- * write straight into the coefficient layout described above.  d_coef is a DEVICE pointer (16-byte aligned,
- * capacity coef_cap_bytes); the result is integer-exact with jb_entropy_decode.  Synchronous.
- * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (restart markers that do not match
- * the frame, more than two DC or AC tables, progressive, grayscale ...) -- use jb_entropy_decode.
- * JB_ERR_FORMAT: corrupt data.  The BATCH decoders (jb_decode_batch, jb_batch_decoder_*) take this
- * path by default for every image it accepts (16 restart intervals / 4 KB of scan or more; measured
- * 1.06x to 2.6x the rate of 16 host threads for a tenth of their CPU time) and fall back to the host
- * decoder per image for whatever it does not take or flags (corrupt data; chunks that did not
- * synchronise); environment JPEGBLK_GPU_HUFFMAN=0 keeps the entropy stage on the host threads
- * (north_star's split), =2 drops the size threshold.  The single-image jb_decode_file /
- * jb_decode_memory take it for files with 256 KB of entropy-coded data or more, where one image's
- * latency is lower on the device (1920x1080 4:4:4: 0.84 ms against 3.9 ms on one host core;
- * 679x451: 1.2-1.7 against 0.7), with JPEGBLK_GPU_HUFFMAN=1 or 2 for every file the device decoders
- * take, with =0 never.  Files with restart intervals: one lane per interval when the intervals are
- * short, else -- like files without DRI -- one lane per 256-byte chunk of every interval. */
+ * is serial host code): the host only parses the headers and removes the byte stuffing.  Every restart
+ * interval of the scan (the DC predictors reset at each restart, jpeg.cpp:419-425, so intervals are
+ * independent; a scan without DRI is one interval) is cut into chunks of 128 bytes, one GPU lane per chunk:
+ * the lanes of a workgroup fall into step with the true symbol sequence in a few passes over LDS
+ * (self-synchronising decoding), a prefix sum gives every chunk its block index, a writing pass decodes
+ * every chunk from its neighbour's final state, stores the coefficients and verifies the chain of chunk
+ * states, and a last pass turns the DC differences into DC values (csrc/jb_huff.hip).  The coefficients land
+ * in the layout described above.  d_coef is a DEVICE pointer (16-byte aligned, capacity coef_cap_bytes); the
+ * result is integer-exact with jb_entropy_decode.  Synchronous.  Takes baseline frames of three components
+ * (any of the four sampling layouts) or one component, with up to three Huffman tables of each kind.
+ * JB_ERR_UNSUPPORTED: a valid stream this decoder does not take (restart markers that do not match the
+ * frame, progressive or multi-scan files, Huffman tables with more long codes than its lookup tables
+ * hold) -- use jb_entropy_decode.  JB_ERR_FORMAT: corrupt data, or chunks that did not fall into step
+ * (dense adversarial data; one retry with more launches is made first) -- jb_entropy_decode is the authority.
+ * The BATCH decoders (jb_decode_batch, jb_batch_decoder_*) take this path by default for every image it
+ * accepts (16 chunks = 2 KB of scan or more) and fall back to the host decoder per image for whatever it
+ * does not take or flags; JPEGBLK_GPU_HUFFMAN=0 keeps the entropy stage on the host threads (north_star's
+ * split), =2 drops the size threshold.  The single-image jb_decode_file / jb_decode_memory take it for files
+ * with 256 KB of entropy-coded data or more, where one image's latency is lower on the device (1920x1080
+ * 4:4:4: 0.51 ms against 3.9 ms on one host core; 679x451: 0.75-0.95 against 0.7), with
+ * JPEGBLK_GPU_HUFFMAN=1 or 2 for every file the device decoder takes, with =0 never. */
 int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,
                              uint16_t *qtabs /* 4*64, may be NULL */, int16_t *d_coef, size_t coef_cap_bytes);
 /* How many images this context has decoded with the entropy stage on the device (through

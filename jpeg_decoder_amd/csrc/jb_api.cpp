@@ -29,6 +29,7 @@
 #include "../../include/jpegblk.h"
 #include "jb_kernels.h"
 #include "jb_huff.h"
+#include "jb_knobs.h"
 
 namespace {
 
@@ -89,6 +90,7 @@ struct DlItem {
 
 struct jb_ctx {
   int device = 0;
+  JbKnobs knobs;                  // the environment as it was when the context was created (jb_knobs.h)
   hipStream_t stream = nullptr;   // primary: uploads + kernels of the ring; device-resident launches with a NULL stream
   hipStream_t stream2 = nullptr;  // downloads of the staging ring
   // Submissions whose entropy stage runs on the device: a decoder launch is latency-bound (a lane
@@ -175,9 +177,7 @@ struct DeviceGuard {
 // device (and land on its NUMA node), not against whatever device the calling thread had current.
 hipError_t build_ring(jb_ctx *ctx) {
   hipError_t e = hipSuccess;
-  // JPEGBLK_SINGLE_STREAM=1 (A/B knob): downloads on the upload stream as well
-  const char *single = getenv("JPEGBLK_SINGLE_STREAM");
-  if (!ctx->stream2 && !(single && single[0] == '1')) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  if (!ctx->stream2) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
   for (int i = 0; e == hipSuccess && i < ctx->n_slots; i++) {
     Slot &s = ctx->slots[i];
     e = hipMalloc(&s.d_coef, round_up((int64_t)ctx->max_coef, 256));
@@ -333,11 +333,7 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   ctx->rgb_alloc = max_rgb_bytes ? (size_t)round_up((int64_t)max_rgb_bytes, 256) : 0;  // device rows are tightly packed
   ctx->n_slots = max_coef_bytes ? n_slots : 0;
   ctx->n_slots_req = n_slots;
-  if (const char *e = getenv("JPEGBLK_STREAM_PAIRS")) {  // A/B knob
-    ctx->n_pairs = atoi(e);
-    if (ctx->n_pairs < 1) ctx->n_pairs = 1;
-    if (ctx->n_pairs > jb_ctx::kMaxPairs) ctx->n_pairs = jb_ctx::kMaxPairs;
-  }
+  ctx->knobs = jb_knobs_read();
   DeviceGuard guard(device_id);
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -458,7 +454,7 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   p.mcus_y = g.mcus_y;
   p.tiles_per_row = (g.mcus_x + per_tile - 1) / per_tile;
   // JPEGBLK_ROW_TILING=1 (debug / A-B knob) forces the row-bound tiling
-  static const bool force_row = getenv("JPEGBLK_ROW_TILING") && getenv("JPEGBLK_ROW_TILING")[0] == '1';
+  const bool force_row = ctx->knobs.row_tiling;
   // linear tiling only where the row-bound one would leave ragged tiles
   p.linear = (force_row || g.mcus_x % per_tile == 0) ? 0 : jbk_linear_ok(b->desc.hs, b->desc.vs, g.mcus_x);
   const int64_t tiles_per_image = p.linear ? ((int64_t)g.mcus_x * g.mcus_y + per_tile - 1) / per_tile
@@ -472,8 +468,7 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   // enabled, and odd widths with tightly packed rows (row stride 3*W) are the common case --
   // measured 1.67x faster than byte stores on 679x451 (tests/test_gpu_parity.py covers both).
   // JPEGBLK_BYTE_STORE=1 forces the byte-store path (test / A-B knob).
-  const char *byte_store = getenv("JPEGBLK_BYTE_STORE");
-  p.fast_store = (byte_store && byte_store[0] == '1') ? 0 : 1;
+  p.fast_store = ctx->knobs.byte_store ? 0 : 1;
   p.chroma_q_equal = (b->desc.qtab_id[1] == b->desc.qtab_id[2]) ? 1 : 0;
   DeviceGuard guard(ctx->device);
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -785,7 +780,7 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     if (rc) return fail(ctx, rc, "bad quantisation table id");
   }
   JB_HIP(ctx, hipMemcpyAsync(s.d_q, s.h_q, 768u * (size_t)n_images, hipMemcpyHostToDevice, up));
-  static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '2';
+  const bool timing = ctx->knobs.timing == 2;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tt0 = timing ? now() : 0;
   JbHuffLayout lay_own;
@@ -872,7 +867,7 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
   JbHuffJob *job = new (std::nothrow) JbHuffJob();
   if (!job) return fail(ctx, JB_ERR_CAPACITY, "out of host memory");
   std::string err;
-  int rc = jb_huff_prepare_(jpeg, jpeg_bytes, job, &err);
+  int rc = jb_huff_prepare_(jpeg, jpeg_bytes, job, &err, ctx->knobs.chunk_bytes);
   if (rc == JB_OK && (size_t)job->geo.coef_bytes > coef_cap_bytes) rc = JB_ERR_CAPACITY, err = "coefficient buffer too small";
   if (rc == JB_OK && ((uintptr_t)d_coef & 15)) rc = JB_ERR_GEOMETRY, err = "coefficient pointer must be a multiple of 16 bytes";
   if (rc != JB_OK) {
@@ -909,7 +904,7 @@ int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes
 // decode(bytes) with the entropy stage on the device: one prepared image through the ring
 // (used by jb_decode_memory, jb_frontend.cpp); the staging ring follows the frame
 int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_stride) {
-  static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '1';
+  const bool timing = ctx->knobs.timing == 1;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = timing ? now() : 0;
   int rc = jb_ctx_reserve(ctx, (size_t)job->geo.coef_bytes, (size_t)job->geo.rgb_bytes);
@@ -1090,10 +1085,9 @@ int jb_check_device_region_(int device, const void *p, size_t bytes) {
   return JB_OK;
 }
 
-int jb_bind_thread_near_device_(int device) {
-  const char *knob = getenv("JPEGBLK_NUMA");
-  if (knob && knob[0] == '0') return 0;
-  const bool forced = knob && knob[0] == '1';
+int jb_bind_thread_near_device_(int device, int numa_knob) {  // numa_knob: JbKnobs::numa of the calling decoder
+  if (numa_knob == 0) return 0;
+  const bool forced = numa_knob == 1;
   const int node = jb_device_numa_node(device);
   if (node < 0) return 0;
   char path[96];
@@ -1140,6 +1134,7 @@ int jb_bind_thread_near_device_(int device) {
 }
 
 void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d) { ctx->last_desc = *d; }
+const JbKnobs *jb_ctx_knobs_(const jb_ctx *ctx) { return &ctx->knobs; }
 
 // used by jb_frontend.cpp to report through the same channel
 int jb_fail_(jb_ctx *ctx, int code, const char *msg) { return fail(ctx, code, "%s", msg); }

@@ -28,6 +28,7 @@
 #include "../../include/jpegblk.h"
 #include "jb_hostmem.h"
 #include "jb_huff.h"
+#include "jb_knobs.h"
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
@@ -44,7 +45,7 @@ void *jb_wait_begin_(jb_ctx *ctx, int ticket);
 // ... and the blocking part, without the lock
 int jb_wait_block_(jb_ctx *ctx, void *event);
 // binds the calling thread to the CPUs of the NUMA node closest to a device (jb_api.cpp)
-int jb_bind_thread_near_device_(int device);
+int jb_bind_thread_near_device_(int device, int numa_knob);
 // JB_OK when [p, p + bytes) is device memory of `device` (jb_api.cpp)
 int jb_check_device_region_(int device, const void *p, size_t bytes);
 
@@ -132,15 +133,7 @@ constexpr int kMaxSlots = 4;
 // 8192x8192 files and stayed inside the run-to-run spread (profiles/r02b/ab_pipeline_depth.txt).  Device-resident
 // output is bound by the latency of a group's launches: there four slots and smaller groups are worth
 // +35 % (1,024 1080p files: 13,400 -> 18,400 images/s) and +25 % (8192x8192: 1,090 -> 1,420), same file.
-// JPEGBLK_LANE_SLOTS = 2..4 overrides.
-int lane_slots(bool device_output) {
-  static const int forced = [] {
-    const char *e = getenv("JPEGBLK_LANE_SLOTS");
-    const int v = e ? atoi(e) : 0;
-    return v <= 0 ? 0 : v < 2 ? 2 : v > kMaxSlots ? kMaxSlots : v;
-  }();
-  return forced ? forced : device_output ? kMaxSlots : 2;
-}
+int lane_slots(bool device_output) { return device_output ? kMaxSlots : 2; }
 
 // what one host thread owns across runs: the pinned buffers its Huffman stage decodes into and,
 // when the caller's pixel buffers are pageable (no arena), pinned pixel staging -- a
@@ -267,6 +260,7 @@ struct Run {
   Arena *arena;
   Shared *dev;
   Totals *tot;
+  const JbKnobs *knobs;  // the decoder's (jb_knobs.h)
 };
 
 // pass 1 (per host thread): parse the headers of its files, so that the buffers can be sized once for
@@ -285,7 +279,7 @@ void parse_one(Parsed &p) {
 }
 
 void parse_pass(const Run &r, int t, std::vector<Parsed> &parsed, size_t *max_coef, size_t *max_rgb, double *t_read) {
-  jb_bind_thread_near_device_(r.device);  // the file bytes are first touched here: keep them on the GPU's node
+  jb_bind_thread_near_device_(r.device, r.knobs->numa);  // the file bytes are first touched here: keep them on the GPU's node
   for (size_t k = 0; k < parsed.size(); k++) {
     const int i = (*r.lists)[(size_t)t][k];
     Parsed &p = parsed[k];
@@ -329,7 +323,7 @@ constexpr int kMaxGroup = 64;
 // slot is reused, the group that used it two steps ago is finished (it has long been through the
 // device by then: entropy decoding takes ~10x the transfers)
 void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, int setup_rc, const std::string &setup_text) {
-  jb_bind_thread_near_device_(r.device);
+  jb_bind_thread_near_device_(r.device, r.knobs->numa);
   const bool use_arena = r.arena && r.arena->base;
   const bool to_device = use_arena && r.arena->on_device;
   double t_entropy = 0, t_wait = 0, t_read = 0;
@@ -363,14 +357,9 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   // decoding on the host -- was measured and is slower than either pure mode: 1,885 images/s against
   // 2,681 host / 2,498 device on PIL 1080p files; large group downloads and many small uploads and
   // downloads at once share the link badly.  Removed.)
-  const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-  const bool dev_entropy = !(knob && knob[0] == '0');
-  const uint32_t min_intervals = (knob && knob[0] == '2') ? 1u : 16u;
-  int dev_max_group = kMaxGroup;  // images per device-entropy group (JPEGBLK_DEV_MAX_GROUP: A/B only)
-  if (const char *e = getenv("JPEGBLK_DEV_MAX_GROUP")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= kMaxGroup) dev_max_group = v;
-  }
+  const bool dev_entropy = r.knobs->gpu_huffman != 0;
+  const uint32_t min_intervals = r.knobs->gpu_huffman == 2 ? 1u : 16u;
+  const int dev_max_group = kMaxGroup;  // images per device-entropy group
   std::vector<uint16_t> qtabs;
   auto index_of = [&](int k) { return (*r.lists)[(size_t)t][(size_t)k]; };
   auto report = [&](int i, int st, const std::string &text) {
@@ -483,7 +472,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       bool eligible = false;
       if (dev_entropy) {
         job.reset(new JbHuffJob());
-        eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_intervals);
+        eligible = jb_huff_prepare_(p.bytes.data(), p.bytes.size(), job.get(), nullptr, r.knobs->chunk_bytes) == JB_OK && jb_huff_worth_it_(*job, min_intervals);
         // the frame this pass reads must be the frame pass 1 sized the group for (a file that changed in between):
         // else the host path below settles the image, with its own capacity checks
         if (eligible && (job->desc.width != p.desc.width || job->desc.height != p.desc.height || job->desc.hs != p.desc.hs ||
@@ -592,6 +581,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
 }  // namespace
 
 struct jb_batch_decoder {
+  JbKnobs knobs = jb_knobs_read();  // the environment as it was when the decoder was created (jb_knobs.h)
   int device = 0;
   std::vector<Lane> lanes;
   Arena own_arena;
@@ -652,12 +642,11 @@ struct jb_batch_decoder {
 
 namespace {
 
-int clamp_threads(int n_threads) {
+int clamp_threads(int n_threads, const JbKnobs &knobs) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 64) n_threads = 64;  // one ring slot each at least (64 host threads decode 30 Gpixel/s: far beyond the link)
   // no more entropy threads than CPUs this process may use (JPEGBLK_OVERSUBSCRIBE=1 lifts that)
-  const char *over = getenv("JPEGBLK_OVERSUBSCRIBE");
-  if (!(over && over[0] == '1') && n_threads > available_cpus()) n_threads = available_cpus();
+  if (!knobs.oversubscribe && n_threads > available_cpus()) n_threads = available_cpus();
   return n_threads;
 }
 
@@ -689,7 +678,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   std::vector<std::vector<int>> lists((size_t)n_threads);
   for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
   Run r{d->device, 0, 0, d->slots(), paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
-        &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot};
+        &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot, &d->knobs};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
   // pass 1: headers, in parallel
@@ -714,10 +703,7 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // every pinned buffer and ring slot holds one large image or a group of small ones: the group
   // figure bounds the coefficient and the pixel side alike (rgb_bytes <= coef_bytes in every layout)
   size_t group_bytes = kGroupBytes;
-  if (const char *e = getenv("JPEGBLK_GROUP_MB")) {  // A/B knob: 0 = one image per submission
-    const long mb = atol(e);
-    group_bytes = mb > 0 ? (size_t)mb << 20 : 0;
-  }
+  if (d->knobs.group_mb >= 0) group_bytes = (size_t)d->knobs.group_mb << 20;  // (JPEGBLK_GROUP_MB; 0 = one image per submission)
   if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
   if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
   // Groups whose entropy stage runs on the device hold about 100 MB of coefficients (JPEGBLK_DEV_GROUP_MB;
@@ -729,10 +715,8 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // output, and the ring slots are a fifth of the size: profiles/r02b/ab_group_size_final.txt.)
   size_t ring_bytes = 0;
   {
-    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    if (!(knob && knob[0] == '0')) {
-      const char *e = getenv("JPEGBLK_DEV_GROUP_MB");
-      const long mb = e ? atol(e) : 96;
+    if (d->knobs.gpu_huffman != 0) {
+      const long mb = d->knobs.dev_group_mb >= 0 ? d->knobs.dev_group_mb : 96;
       ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
       size_t share = (size_t)((n_paths + n_threads - 1) / (n_threads > 0 ? n_threads : 1));
       if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;
@@ -770,7 +754,7 @@ extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_
                                        size_t max_rgb_bytes, jb_batch_decoder **out) {
   if (!out) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create: out is NULL");
   *out = nullptr;
-  return create_single(device_id, clamp_threads(n_threads), max_coef_bytes, max_rgb_bytes, out);
+  return create_single(device_id, clamp_threads(n_threads, jb_knobs_read()), max_coef_bytes, max_rgb_bytes, out);
 }
 
 extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_devices, int n_threads,
@@ -778,7 +762,7 @@ extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_device
   if (!out || !device_ids) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create_multi: NULL pointer");
   *out = nullptr;
   if (n_devices < 1 || n_devices > 64) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_create_multi: 1..64 devices");
-  n_threads = clamp_threads(n_threads);
+  n_threads = clamp_threads(n_threads, jb_knobs_read());
   if (n_threads < n_devices) n_threads = n_devices;  // every device needs a host thread to feed it
   jb_batch_decoder *top = new jb_batch_decoder();
   top->device = device_ids[0];

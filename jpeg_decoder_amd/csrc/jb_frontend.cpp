@@ -35,10 +35,12 @@
 #include "jb_hostmem.h"
 #include "jb_huff.h"
 #include "jb_huff_core.h"
+#include "jb_knobs.h"
 
 struct jb_ctx;
 int jb_fail_(jb_ctx *ctx, int code, const char *msg);
 void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d);
+const JbKnobs *jb_ctx_knobs_(const jb_ctx *ctx);  // jb_api.cpp
 extern "C" int jb_decode_job_(jb_ctx *ctx, const JbHuffJob *job, uint8_t *rgb, int64_t rgb_stride);  // jb_api.cpp
 // general front end (jb_frontend_ext.cpp): progressive, grayscale, multi-scan files
 int jb_ext_decode_(const uint8_t *jpeg, size_t n, jb_image_desc *desc, uint16_t *qtabs, int16_t *coef,
@@ -298,7 +300,7 @@ bool jb_huff_fill_table_(const uint8_t counts[17], const uint8_t *symbols, bool 
 }
 
 // Ready one image for the device-side entropy decoder (jb_huff.hip): see jb_huff.h.
-int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err) {
+int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err, uint32_t chunk_knob) {
   Frame *fr = new Frame();
   Err e;
   int rc = parse_headers(jpeg, jpeg_bytes, *fr, e, true);
@@ -371,12 +373,8 @@ int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std
   if ((uint64_t)n_mcus * job->img.nb >= (1u << 24)) return done(JB_ERR_UNSUPPORTED, "more blocks than the device decoder's 24-bit block index holds: host decoder");
   job->img.n_blocks = (uint32_t)(n_mcus * job->img.nb);
   // Every restart interval (a scan without DRI is one interval) is cut into chunks from its own first byte, one
-  // lane per chunk (jb_huff.h).  JPEGBLK_CHUNK_BYTES = 64 | 128 forces a size (tests, A/B runs).
-  uint32_t chunk_bytes = kJbChunkBytes;
-  if (const char *e = getenv("JPEGBLK_CHUNK_BYTES")) {
-    const int v = atoi(e);
-    if (v == 64 || v == 128) chunk_bytes = (uint32_t)v;
-  }
+  // lane per chunk (jb_huff.h); the caller's knob may force the size (JPEGBLK_CHUNK_BYTES, jb_knobs.h: tests, A/B runs)
+  const uint32_t chunk_bytes = (chunk_knob == 64 || chunk_knob == 128) ? chunk_knob : kJbChunkBytes;
   job->img.chunk_bytes = chunk_bytes;
   {
     uint64_t n_chunks = 0;
@@ -450,17 +448,17 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   // below, which gives the precise answer.
   {
     constexpr size_t kAutoDeviceScan = (size_t)256 << 10;
-    const char *knob = getenv("JPEGBLK_GPU_HUFFMAN");
-    const bool forced = knob && (knob[0] == '1' || knob[0] == '2');
-    const bool automatic = !knob || (knob[0] != '0' && !forced);
-    const uint32_t min_int = (knob && knob[0] == '2') ? 1u : 16u;
+    const JbKnobs &knobs = *jb_ctx_knobs_(ctx);  // (read when the context was created: jb_knobs.h)
+    const bool forced = knobs.gpu_huffman == 1 || knobs.gpu_huffman == 2;
+    const bool automatic = knobs.gpu_huffman < 0;
+    const uint32_t min_int = knobs.gpu_huffman == 2 ? 1u : 16u;
     if (forced || (automatic && jpeg_bytes >= kAutoDeviceScan)) {
       // JPEGBLK_TIMING=1: where one decode(bytes) through the device path spends its time, on stderr
-      static const bool timing = getenv("JPEGBLK_TIMING") && getenv("JPEGBLK_TIMING")[0] == '1';
+      const bool timing = knobs.timing == 1;
       auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
       const double t0 = timing ? now() : 0;
       std::unique_ptr<JbHuffJob> job(new JbHuffJob());
-      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr) == JB_OK && jb_huff_worth_it_(*job, min_int) &&
+      if (jb_huff_prepare_(jpeg, jpeg_bytes, job.get(), nullptr, knobs.chunk_bytes) == JB_OK && jb_huff_worth_it_(*job, min_int) &&
           (forced || job->scan_len >= kAutoDeviceScan)) {
         const double t1 = timing ? now() : 0;
         uint8_t *out = jb_alloc_pixels_((size_t)job->geo.rgb_bytes);

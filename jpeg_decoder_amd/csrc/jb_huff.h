@@ -168,7 +168,8 @@ struct JbHuffJob {
 // decoder does not take (markers that do not match the frame, Huffman tables whose long codes do
 // not fit the second-level pool, a frame for the general front end) -- use the host decoder.
 // Other negatives: the header errors of jb_entropy_decode.
-int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err);
+// chunk_bytes: 0 = the default (kJbChunkBytes), else 64 or 128 (JbKnobs::chunk_bytes of the calling object).
+int jb_huff_prepare_(const uint8_t *jpeg, size_t jpeg_bytes, JbHuffJob *job, std::string *err, uint32_t chunk_bytes = 0);
 
 // Where the pieces of a packed submission lie in its blob:
 //   [JbHuffImage x n][JbHuffWg x n_wg][JbHuffWg x n_sync_wg][JbHuffTables x n_sets][starts][chunk descriptors][scans, 16-byte aligned each]

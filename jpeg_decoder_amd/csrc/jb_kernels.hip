@@ -82,15 +82,17 @@ __device__ __forceinline__ float kf(uint32_t bits) { return __builtin_bit_cast(f
 // (220 -> 210 us), neutral to +3 % for the stores of the other layouts.  The per-lane block
 // loads of the direct path must NOT be nt: their 8 instructions re-use each 128-B line through
 // L1, and nt made them 1.9x slower (154 -> 293 us on 4:2:0).
-#ifndef JB_LOAD_AUX
+// (JB_LAB: tools/build_variant.sh builds measurement variants of this file -- other cache policies, stages
+// skipped at run time -- next to the product; the product is always built without it)
+#if !defined(JB_LAB) || !defined(JB_LOAD_AUX)
+#undef JB_LOAD_AUX
 #define JB_LOAD_AUX 2
 #endif
-#ifndef JB_STORE_AUX
+#if !defined(JB_LAB) || !defined(JB_STORE_AUX)
+#undef JB_STORE_AUX
 #define JB_STORE_AUX 2
 #endif
-#ifndef JB_SCHED_FENCE
 #define JB_SCHED_FENCE() ((void)0)
-#endif
 // Coded blocks per tile = lanes per workgroup: the smallest whole number of MCUs that fills whole
 // waves with ONE component each.  4:4:4 (3 blocks per MCU) and 4:2:0 (6): 192 lanes = 64 / 32 MCUs
 // (in 4:2:0 Cb and Cr share the third wave).  4:2:2 and 4:4:0 (4 blocks per MCU): 256 lanes = 64
@@ -101,13 +103,7 @@ constexpr int tile_blocks(int hs, int vs) { return hs * vs == 2 ? 256 : 192; }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also wait for the
 // global stores of the previous colour phase (vmcnt(0)), putting HBM write latency on the
 // critical path between the two phases.
-__device__ __forceinline__ void lds_barrier() {
-#ifdef JB_EXPERIMENT_NO_BARRIER  // timing experiment only: results are wrong without barriers
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One 1-D pass of the AAN network (reference jpeg.cpp:598-662 / 666-730), in place, each
 // output truncated toward zero exactly where the reference stores a float into an int.
@@ -212,24 +208,25 @@ typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 
-// Timing experiments (tools/ builds only, never the product): a stage is skipped at run time
-// through a condition the compiler cannot fold, so the code and its registers stay.
-#ifdef JB_EXP_NO_LOAD
+// Measurement variants (tools/ablate.sh through tools/build_variant.sh -DJB_LAB -DJB_EXP_NO_...): a stage is
+// skipped at run time through a condition the compiler cannot fold, so the code and its registers stay.  The
+// product is built without JB_LAB: every stage always runs.
+#if defined(JB_LAB) && defined(JB_EXP_NO_LOAD)
 #define JB_DO_LOAD(p) ((p).reserved == 777)
 #else
 #define JB_DO_LOAD(p) true
 #endif
-#ifdef JB_EXP_NO_IDCT
+#if defined(JB_LAB) && defined(JB_EXP_NO_IDCT)
 #define JB_DO_IDCT(p) ((p).reserved == 777)
 #else
 #define JB_DO_IDCT(p) true
 #endif
-#ifdef JB_EXP_NO_COLOUR
+#if defined(JB_LAB) && defined(JB_EXP_NO_COLOUR)
 #define JB_DO_COLOUR(p) ((p).reserved == 777)
 #else
 #define JB_DO_COLOUR(p) true
 #endif
-#ifdef JB_EXP_NO_STORE
+#if defined(JB_LAB) && defined(JB_EXP_NO_STORE)
 #define JB_DO_STORE(p) ((p).reserved == 777)
 #else
 #define JB_DO_STORE(p) true
@@ -278,14 +275,6 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
   static_assert(CR_OFF + 4 * CW * 4 == kStripBytes, "strips must fill the strip area exactly");
   static_assert(NYT % 64 == 0, "whole luma waves: no wave mixes luma and chroma blocks");
   constexpr bool kPermChroma = (VS == 2) && (NYT % 64 == 0);  // 4:2:0: chroma blocks fill a whole wave
-  // JB_SPLIT_ROWPASS (experiment): the row passes of register rows 4-7 -- what the second colour
-  // phase consumes -- run after the first phase's colour loop instead of before it, so that the
-  // first stores of a workgroup leave earlier and that quarter of the IDCT overlaps them
-#ifdef JB_SPLIT_ROWPASS
-  constexpr bool kSplitRows = (VS == 1) || kPermChroma;
-#else
-  constexpr bool kSplitRows = false;
-#endif
   // The 4-pixel group that straddles the right image edge (width % 4 != 0): two stores from the packed
   // words in the linear tiling -- the one small and odd-sized images take, where every row has such a
   // group -- and the byte-store loop elsewhere: in the row-bound instantiations (4096 / 8192-pixel
@@ -307,15 +296,7 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
   // elsewhere -- nothing is re-read, so there is no L2 locality to win, and eight separate write
   // windows cost HBM page locality (tools/probe_store2.hip: the same 403 MB written by one
   // advancing window reach 6.4 TB/s, by many separate streams 5.2 TB/s).
-  int tile;
-#ifdef JB_EXPERIMENT_XCD_BANDS  // measured 1-3.5 % slower (see the comment above): not the default
-  {
-    const int nwg = p.n_tiles, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  }
-#else
-  tile = blockIdx.x;
-#endif
+  const int tile = blockIdx.x;
   const int img = tile / tiles_per_image;
   const int rem = tile - img * tiles_per_image;
   // Two tilings.  Linear (p.linear, the default): a tile is 192/NB consecutive MCUs of the image's
@@ -444,7 +425,7 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
              v[6 * 8 + i], v[7 * 8 + i]), JB_SCHED_FENCE();
   }
 #pragma unroll
-  for (int k = 0; k < (kSplitRows ? 4 : 8); k++)  // row pass, jpeg.cpp:664-731
+  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
     aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
            v[k * 8 + 6], v[k * 8 + 7]), JB_SCHED_FENCE();
   }
@@ -486,14 +467,6 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
 
 #pragma unroll
   for (int phase = 0; phase < 2; phase++) {
-    if (phase == 1 && kSplitRows && JB_DO_IDCT(p)) {
-#pragma unroll
-      for (int i = 32; i < 64; i++) asm volatile("" : "+v"(v[i]));  // pins these row passes here
-#pragma unroll
-      for (int k = 4; k < 8; k++)
-        aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5],
-               v[k * 8 + 6], v[k * 8 + 7]);
-    }
     if (phase == 1) lds_barrier();  // phase-0 colour reads are done: the strips may be rewritten
     // Every lane contributes rows 4*phase..4*phase+3 of its block (so half of every block is
     // consumed per phase and only 32 values wait in registers).  Luma block-row bv lands in
@@ -647,8 +620,7 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   // hipGetLastError below must report THIS launch: an error left in the thread's error slot by an
   // unrelated earlier call (a failed attribute query, say) is not this launch's
   (void)hipGetLastError();
-  // JPEGBLK_EXTRA_LDS (experiment): unused dynamic LDS per workgroup, to cap workgroups per CU
-  static const unsigned extra_lds = getenv("JPEGBLK_EXTRA_LDS") ? (unsigned)atoi(getenv("JPEGBLK_EXTRA_LDS")) : 0u;
+  constexpr unsigned extra_lds = 0;
   if (kCanLinear && p.linear) {
     if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, extra_lds, stream, p);
     else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, extra_lds, stream, p);

@@ -75,8 +75,11 @@ def main():
     t0 = time.time()
     n_batches = n_images = n_bad = n_dev = 0
     pixels = 0
+    # the reference context keeps the entropy stage on the host (a context reads its knobs when it is created)
+    os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
+    one_ctx = jb.Context(0)
     os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
-    with tempfile.TemporaryDirectory(dir="/tmp") as d, jb.Context(0) as one:
+    with tempfile.TemporaryDirectory(dir="/tmp") as d, one_ctx as one:
         while time.time() - t0 < args.seconds:
             distinct = []
             for k in range(int(rng.integers(1, 7))):
@@ -87,12 +90,10 @@ def main():
                 with open(p, "wb") as f:
                     f.write(data)
                 # what it must decode to: the single-image decode, entropy stage on the host
-                os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
                 try:
                     want = one.decode_memory(data)
                 except jb.JbError as e:
                     want = e.status
-                os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
                 # the arena space the batch decoder may take for it (also for an image whose scan turns out corrupt)
                 try:
                     dsc = jb.entropy_decode(data, headers_only=True)[0]

@@ -18,6 +18,7 @@
 
 #include "../../include/jpegblk.h"
 #include "../../jpeg_decoder_amd/csrc/jb_huff.h"
+#include "../../jpeg_decoder_amd/csrc/jb_knobs.h"
 
 extern "C" long jw_encode_ex(const int16_t *coef, int width, int height, int hs, int vs, const uint16_t *qtabs,
                              const int *qtab_id, const uint8_t *dht, int restart_interval, int dqt16, int scan_mode,
@@ -31,6 +32,10 @@ int jb_fail_(jb_ctx *, int code, const char *msg) {
   return code;
 }
 void jb_ctx_set_last_desc_(jb_ctx *, const jb_image_desc *) {}
+const JbKnobs *jb_ctx_knobs_(const jb_ctx *) {
+  static const JbKnobs k;
+  return &k;
+}
 extern "C" {
 const char *jb_last_error(const jb_ctx *) { return g_err.c_str(); }
 void *jb_pinned_alloc(size_t n) { return malloc(n); }

@@ -25,6 +25,7 @@ static thread_local std::vector<int> tl_pass_no;
 #define JBH_TRACE_PASS_END(pass) (tl_passes.push_back(tl_steps), tl_pass_no.push_back((int)(pass)), tl_steps = 0)
 
 #include "../../jpeg_decoder_amd/csrc/jb_huff.hip"
+#include "../../jpeg_decoder_amd/csrc/jb_knobs.h"
 
 alignas(16) uint8_t lds[160 * 1024];
 // per launch (in order): lane-steps, and wave-steps = sum over the waves' passes of the longest lane (what a wave pays)
@@ -116,7 +117,7 @@ int main(int argc, char **argv) {
     files.push_back(read_file(p));
     std::unique_ptr<JbHuffJob> job(new JbHuffJob());
     std::string err;
-    const int rc = jb_huff_prepare_(files.back().data(), files.back().size(), job.get(), &err);
+    const int rc = jb_huff_prepare_(files.back().data(), files.back().size(), job.get(), &err, jb_knobs_read().chunk_bytes);
     if (rc != JB_OK) {
       printf("%s: not taken by the device decoder (%d: %s)\n", p, rc, err.c_str());
       files.pop_back();

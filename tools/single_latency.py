@@ -74,14 +74,18 @@ def main():
     if args.sub:
         sizes = [x for x in sizes if x[2] == args.sub]
     rows = []
-    with jb.Context(0) as ctx:
+    # (a context reads its knobs when it is created: one context per mode)
+    os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
+    ctx_host = jb.Context(0)
+    os.environ["JPEGBLK_GPU_HUFFMAN"] = "2"
+    ctx = jb.Context(0)
+    os.environ.pop("JPEGBLK_GPU_HUFFMAN", None)
+    with ctx_host, ctx:
         for w, h, sub in sizes:
             for dri in [int(v) for v in args.dri.split(",")]:
                 src, data = make(w, h, sub, dri)
                 reps = 8 if w * h < 3e7 else 4
-                os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
-                t_host, ref = timed(ctx, data, reps)
-                os.environ["JPEGBLK_GPU_HUFFMAN"] = "2"
+                t_host, ref = timed(ctx_host, data, reps)
                 before = ctx.device_entropy_images
                 t_dev, px = timed(ctx, data, reps)
                 took = ctx.device_entropy_images - before
