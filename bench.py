@@ -222,8 +222,7 @@ def end_to_end(jb, np, torch, dist, dev_index, reduce_device, rank, world, tmpdi
                 with jb.BatchDecoder(threads, dev_index, g.coef_bytes, g.rgb_bytes, arena_bytes=sub * per) as dec:
                     dec.run(files[:min(threads, sub)], keep_pixels=False)
                     walls = []
-                    # pass 0 is the checked one and is not timed (the comparisons between its runs leave the device
-                    # idle, and a run that follows an idle gap pays 60-100 ms of wake-up); then the timed passes
+                    # pass 0 is the checked one and is not timed (it is also the decoder's first run); then the timed passes
                     reps = 3 if n_mine * per <= (16 << 30) else 2
                     for k in range(reps + 1):
                         if dist is not None:

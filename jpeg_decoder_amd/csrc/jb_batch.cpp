@@ -656,8 +656,24 @@ int create_single(int device_id, int n_threads, size_t max_coef_bytes, size_t ma
   d->lanes.resize((size_t)n_threads);
   // the context exists from the start (also when the buffers are sized lazily), so that a
   // missing or unusable device is reported here
-  int rc = (max_coef_bytes && max_rgb_bytes) ? d->ensure_all(max_coef_bytes, max_rgb_bytes, n_threads)
-                                             : d->ensure_ctx(128, 192);
+  // With sizes given, everything a batch of such images needs is built HERE -- the staging of the host path
+  // (groups of kGroupBytes) and, where the entropy stage runs on the device, ring slots for groups of
+  // JPEGBLK_DEV_GROUP_MB -- so that the first run does not spend 45-120 ms growing them (a decoder created
+  // with (0, 0) sizes itself from its first batch instead).
+  int rc;
+  if (max_coef_bytes && max_rgb_bytes) {
+    size_t group = kGroupBytes;
+    if (d->knobs.group_mb >= 0) group = (size_t)d->knobs.group_mb << 20;
+    const size_t mc = max_coef_bytes < group ? group : max_coef_bytes, mr = max_rgb_bytes < group ? group : max_rgb_bytes;
+    size_t ring = 0;
+    if (d->knobs.gpu_huffman != 0) {
+      ring = (size_t)(d->knobs.dev_group_mb >= 0 ? d->knobs.dev_group_mb : 96) << 20;
+      if (ring > (size_t)kMaxGroup * mc) ring = (size_t)kMaxGroup * mc;
+    }
+    rc = d->ensure_all(mc, mr, n_threads, ring, ring);
+  } else {
+    rc = d->ensure_ctx(128, 192);
+  }
   if (rc != JB_OK) {
     std::string text = jb_last_error(nullptr);
     jb_batch_decoder_destroy(d);
