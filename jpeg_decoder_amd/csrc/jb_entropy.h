@@ -386,6 +386,52 @@ struct CleanScan {
   int n_intervals() const { return (int)start.size() - 1; }
 };
 
+// A stretch of a scan without a branch per 0xFF: 32 bytes per step, the stuffed zero bytes squeezed out of each
+// 8-byte word with PEXT.  A synthetic stream has one FF00 per ~30 bytes (a photograph one per ~250), and a loop
+// that branches on every one of them pays a misprediction each time: 23 ns per pair, 0.45 ms for a 1080p file of
+// tools/jpegwriter, which was most of what jb_huff_prepare_ cost.  Works through at most `limit` bytes; stops in
+// front of the 32 bytes that hold a 0xFF followed by anything other than 0x00 (RSTn, EOI, fill bytes) and in front
+// of the last 32 bytes of the buffer; p / o are left where the byte-exact loop of unstuff() can take over.
+// Returns the number of stuffed bytes it removed (what unstuff() chooses its loop by).
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2,popcnt"))) inline size_t unstuff_words_x86(const uint8_t *&p_io, const uint8_t *end,
+                                                                             uint8_t *&o_io, size_t limit) {
+  typedef long long v4di __attribute__((vector_size(32)));
+  typedef char v32qi __attribute__((vector_size(32)));
+  const uint8_t *p = p_io;
+  uint8_t *o = o_io;
+  const uint8_t *const stop = (size_t)(end - p) > limit ? p + limit : end;
+  size_t removed = 0;
+  uint64_t carry = 0;  // 1 when the byte in front of these 32 was a 0xFF (already written out)
+  const v32qi all_ff = (v32qi)(v4di){-1, -1, -1, -1}, all_00 = (v32qi)(v4di){0, 0, 0, 0};
+  while (p + 32 <= stop) {
+    v32qi v;
+    memcpy(&v, p, 32);
+    const uint32_t ff = (uint32_t)__builtin_ia32_pmovmskb256((v32qi)(v == all_ff));
+    const uint32_t zz = (uint32_t)__builtin_ia32_pmovmskb256((v32qi)(v == all_00));
+    const uint64_t second64 = ((uint64_t)ff << 1) | carry;  // bytes that follow a 0xFF
+    const uint32_t second = (uint32_t)second64;
+    if (second & ~zz) break;                                // ... and are not the stuffed zero: rare, the caller's
+    const uint32_t keep = ~second;
+    for (int j = 0; j < 4; j++) {
+      const uint64_t kb = (keep >> (8 * j)) & 0xff;
+      const uint64_t m = __builtin_ia32_pdep_di(kb, 0x0101010101010101ull) * 0xffull;  // bits -> whole bytes
+      uint64_t w;
+      memcpy(&w, p + 8 * j, 8);
+      const uint64_t packed = __builtin_ia32_pext_di(w, m);
+      memcpy(o, &packed, 8);  // up to 8 bytes ahead of the data kept: CleanScan::kPad covers it
+      o += __builtin_popcountll(kb);
+    }
+    removed += (size_t)__builtin_popcount(second);
+    p += 32;
+    carry = second64 >> 32;
+  }
+  if (carry) p -= 1, o -= 1;  // the 0xFF in front belongs to what follows: hand it back as well
+  p_io = p, o_io = o;
+  return removed;
+}
+#endif
+
 // [p, end): the entropy-coded bytes from the first byte after SOS to the end of the file buffer;
 // stops at EOI / any marker that is not RSTn (reference equivalent: readImageData, file.hpp:59-104)
 inline void unstuff(const uint8_t *p, const uint8_t *end, CleanScan &cs) {
@@ -394,7 +440,31 @@ inline void unstuff(const uint8_t *p, const uint8_t *end, CleanScan &cs) {
   uint8_t *o = base;
   cs.start.clear();
   cs.start.push_back(0);
+  // Two loops, chosen per 4 KiB by how many 0xFF the last 4 KiB held: memchr + memcpy per run of plain bytes
+  // (7 GB/s on a photograph), or the word loop above (3x faster than that on a dense synthetic stream, slower on
+  // a sparse one).
+  constexpr size_t kWindow = 4096, kDenseOneIn = 96;
+  bool dense = false;
+#if defined(__x86_64__)
+  static const bool have_words =
+      __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
+  dense = have_words;
+#else
+  constexpr bool have_words = false;
+#endif
+  const uint8_t *win = p;
+  size_t events = 0;
   while (p < end) {
+#if defined(__x86_64__)
+    if (dense) {
+      const uint8_t *const p0 = p;
+      const size_t removed = unstuff_words_x86(p, end, o, kWindow);
+      if ((size_t)(p - p0) >= kWindow - 64) dense = removed * kDenseOneIn >= (size_t)(p - p0);
+      win = p, events = 0;
+      if (p >= end) break;
+    }
+#endif
+    // byte-exact from here to the next 0xFF, and what that 0xFF means
     const uint8_t *q = (const uint8_t *)memchr(p, 0xff, (size_t)(end - p));
     if (!q) q = end;
     memcpy(o, p, (size_t)(q - p));
@@ -412,6 +482,11 @@ inline void unstuff(const uint8_t *p, const uint8_t *end, CleanScan &cs) {
       p += 2;
     } else {
       break;  // EOI or any other marker ends the scan
+    }
+    events++;
+    if (have_words && (size_t)(p - win) >= kWindow) {
+      dense = events * kDenseOneIn >= (size_t)(p - win);
+      win = p, events = 0;
     }
   }
   cs.start.push_back((size_t)(o - base));

@@ -373,6 +373,24 @@ def test_front_end_fuzz_under_sanitizers(tmp_path):
     assert n > 500, r.stdout
 
 
+def test_unstuff_word_loop_equals_the_byte_loop():
+    """csrc/jb_entropy.h unstuff(): the PEXT word loop and the memchr loop, switched per 4 KiB by the density of
+    0xFF, against the one-byte-at-a-time rule (reference file.hpp:59-104) on random scans with restart markers,
+    fill bytes, EOI in the middle and a lone 0xFF at the end; under ASan + UBSan with exact-length buffers."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    d = os.path.join(ROOT, "tools", "fuzz")
+    b = subprocess.run(["make", "-C", d, "unstuff_check"], capture_output=True, text=True)
+    if b.returncode != 0 and ("cannot find -lasan" in b.stderr or "cannot find -lubsan" in b.stderr or "libasan" in b.stderr):
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([os.path.join(d, "unstuff_check"), "4", "2024"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert int(r.stdout.split()[1]) > 1000, r.stdout
+
+
 # ---- beyond the reference: progressive, grayscale (csrc/jb_frontend_ext.cpp) ----
 
 def _smooth_image(w, h, seed=3):
