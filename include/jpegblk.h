@@ -54,7 +54,7 @@
  *   JPEGBLK_DEV_GROUP_MB   MB of coefficients per group whose entropy stage runs on the device (96)
  *   JPEGBLK_NUMA           0 = leave the host threads' CPU affinity alone, 1 = always bind them to the GPU's node
  *   JPEGBLK_OVERSUBSCRIBE  1 = allow more host threads than CPUs the process may use
- *   JPEGBLK_TIMING         1 | 2 = where one decode(bytes) / one device-entropy submission spends its time (stderr)
+ *   JPEGBLK_TIMING         1 | 2 | 3 = where one decode(bytes) / one device-entropy submission / one batch run spends its time (stderr)
  *   JPEGBLK_HW_QUEUES      read when the library is LOADED: hardware queues to ask the HIP runtime for
  *                          (GPU_MAX_HW_QUEUES; default 16, 0 = the runtime's default).  Process-wide, and only
  *                          effective before HIP initialises: an application that initialises HIP first sets
@@ -293,6 +293,23 @@ int jb_batch_decoder_create(int device_id, int n_threads, size_t max_coef_bytes,
 int jb_batch_decoder_run(jb_batch_decoder *dec, const char *const *paths, int n_paths, uint8_t **rgb,
                          int32_t *widths, int32_t *heights, int *statuses, double *times);
 void jb_batch_decoder_destroy(jb_batch_decoder *dec);
+/* Batches in a stream: submit returns at once and the batch runs on the decoder's own host threads; collect
+ * waits for it and returns what jb_batch_decoder_run would have (status, and `times` if given).  Up to TWO
+ * batches are in flight -- a third submit is refused with JB_ERR_STATE until the older one has been collected --
+ * so that the start-up of batch k+1 (reading headers, the first groups' entropy stage and uploads) runs under
+ * the tail of batch k (its last kernels and downloads): the seam the reference leaves synchronous per image
+ * (jpeg.cpp:785-788) overlapped per batch as well.  Batches alternate between two sides, each with its own
+ * host threads, staging and ring on the same device(s); the second side is built by the first submit (tens of
+ * milliseconds, as creating a decoder).  Outputs: without an arena as for run (malloc'ed, jb_free); with a
+ * pinned arena each side has one of the size given to jb_batch_decoder_set_arena, and with device regions side 0
+ * writes into the first half of every region and side 1 into the second -- rgb[i] of batch k stay valid until
+ * batch k+2 is submitted.  rgb / widths / heights / statuses must stay valid until the batch is collected (the
+ * path strings are copied by submit).  jb_batch_decoder_run / _set_arena / _set_device_output[s] are refused
+ * with JB_ERR_STATE while a batch is in flight; jb_batch_decoder_destroy waits for batches still running.
+ * One thread at a time calls submit / collect on a decoder. */
+int jb_batch_decoder_submit(jb_batch_decoder *dec, const char *const *paths, int n_paths, uint8_t **rgb,
+                            int32_t *widths, int32_t *heights, int *statuses, int *ticket);
+int jb_batch_decoder_collect(jb_batch_decoder *dec, int ticket, double *times);
 /* One decoder over SEVERAL devices of the node (BASELINE.json configs 4-5 as ONE call; images are
  * independent -- reference jpeg.cpp:574-589 touches each block on its own, jpeg.cpp:916-929 decodes
  * one image per process -- so file i goes to device_ids[i % n_devices], no data crosses devices).

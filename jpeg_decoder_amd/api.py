@@ -128,6 +128,8 @@ def lib():
     L.jb_batch_decoder_run.argtypes = [vp] + L.jb_decode_batch.argtypes[1:3] + L.jb_decode_batch.argtypes[4:]
     L.jb_batch_decoder_destroy.argtypes = [vp]
     L.jb_batch_decoder_destroy.restype = None
+    L.jb_batch_decoder_submit.argtypes = L.jb_batch_decoder_run.argtypes[:-1] + [ctypes.POINTER(ctypes.c_int)]
+    L.jb_batch_decoder_collect.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     L.jb_poll.argtypes = [vp, ctypes.c_int]
     L.jb_submit_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), ctypes.c_int, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
     L.jb_batch_decoder_set_arena.argtypes = [vp, ctypes.c_size_t]
@@ -337,6 +339,7 @@ class BatchDecoder:
             _check(lib().jb_batch_decoder_create(device, n_threads, max_coef_bytes, max_rgb_bytes, ctypes.byref(self._h)))
         self._arena = False
         self._device_out = False
+        self._flights = {}
         if arena_bytes:
             _check(lib().jb_batch_decoder_set_arena(self._h, arena_bytes))
             self._arena = True
@@ -380,10 +383,49 @@ class BatchDecoder:
              "error": lib().jb_last_error(None).decode(errors="replace") if rc else ""}
         return [int(rgb[i] or 0) for i in range(n)], [(w[i], h[i]) for i in range(n)], list(st), t
 
+    # -- batches in a stream (jb_batch_decoder_submit / _collect): two in flight -----------------
+    def submit(self, paths):
+        """-> a ticket (keeps the batch's arrays alive); the batch runs while the caller prepares the next one."""
+        n = len(paths)
+        t = {"n": n, "paths": (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths]), "rgb": (ctypes.c_void_p * n)(),
+             "w": (ctypes.c_int32 * n)(), "h": (ctypes.c_int32 * n)(), "st": (ctypes.c_int * n)(), "id": ctypes.c_int(-1)}
+        _check(lib().jb_batch_decoder_submit(self._h, t["paths"], n, t["rgb"], t["w"], t["h"], t["st"], ctypes.byref(t["id"])))
+        # the library writes into these arrays until the batch is collected (or the decoder destroyed): the decoder
+        # object holds them as well, so a ticket the caller drops cannot free them under a running batch
+        self._flights[t["id"].value] = t
+        return t
+
+    def collect(self, ticket, keep_pixels=True, on_image=None):
+        """-> what run() returns (host output: arrays / None; with an arena the pixels are views' copies), or, with
+        device output set, what run_to_device() returns."""
+        times = (ctypes.c_double * 4)()
+        rc = lib().jb_batch_decoder_collect(self._h, ticket["id"], times)
+        if rc != -7:   # (JB_ERR_STATE: no such batch -- nothing was collected)
+            self._flights.pop(ticket["id"].value, None)
+        n, rgb, w, h, st = ticket["n"], ticket["rgb"], ticket["w"], ticket["h"], ticket["st"]
+        t = {"wall_s": times[0], "entropy_s": times[1], "device_s": times[2], "read_s": times[3], "rc": rc,
+             "error": lib().jb_last_error(None).decode(errors="replace") if rc else ""}
+        if self._device_out:
+            return [int(rgb[i] or 0) for i in range(n)], [(w[i], h[i]) for i in range(n)], list(st), t
+        out = []
+        for i in range(n):
+            if rgb[i]:
+                m = w[i] * h[i] * 3
+                view = np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).reshape(h[i], w[i], 3)
+                if on_image is not None:
+                    on_image(i, view)
+                out.append(view.copy() if keep_pixels else (w[i], h[i]))
+                if not self._arena:
+                    lib().jb_free(rgb[i])
+            else:
+                out.append(None)
+        return out, list(st), t
+
     def close(self):
         if self._h:
-            lib().jb_batch_decoder_destroy(self._h)
+            lib().jb_batch_decoder_destroy(self._h)   # (waits for batches still in flight)
             self._h = ctypes.c_void_p()
+            self._flights.clear()
 
     def __enter__(self):
         return self

@@ -11,6 +11,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <hip/hip_runtime_api.h>
@@ -74,8 +76,9 @@ struct Slot {
   int ticket = -1;
 };
 
-// one download handed to the context's download thread
+// one download handed to the device's download thread
 struct DlItem {
+  jb_ctx *ctx;
   Slot *slot;
   void *dst;
   const void *src;
@@ -84,6 +87,24 @@ struct DlItem {
   void *status_dst;
   const void *status_src;
   size_t status_bytes;
+};
+
+// Downloads of the submissions whose entropy stage runs on the device, in the order their KERNELS FINISH, back to
+// back on one stream -- one engine per DEVICE, shared by every context on it (two batch decoders on one GPU, the
+// two sides of jb_batch_decoder_submit): the link has one direction to give, and copies of several contexts issued
+// side by side share it at 45 GB/s where one stream gets 57.  Issued by the submitting threads on their own
+// streams, several copies shared the link the same way; on one dedicated stream in SUBMISSION order a copy whose
+// kernels were still queued held up every copy behind it.  So the submitter records `computed` behind its kernels
+// and hands the copy to this thread, which issues whichever is ready, two deep.
+struct DlEngine {
+  int device = 0;
+  int refs = 0;  // contexts holding it (under g_dl_mu)
+  std::thread thread;
+  std::mutex mu;
+  std::condition_variable cv, issued_cv;
+  std::deque<DlItem> queue;
+  bool stop = false;
+  hipStream_t stream = nullptr;
 };
 
 }  // namespace
@@ -122,19 +143,9 @@ struct jb_ctx {
   long long n_device_entropy = 0;  // images whose entropy stage ran on the device (jb_huff.hip)
   jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
-  // Downloads of the submissions whose entropy stage runs on the device, in the order their KERNELS FINISH, back to
-  // back on one stream.  Issued by the submitting threads on their own streams, several copies shared the link at
-  // once (45 GB/s while busy against the 57 GB/s one stream gets); on one dedicated stream in SUBMISSION order a copy
-  // whose kernels were still queued held up every copy behind it.  So the submitter records `computed` behind its
-  // kernels and hands the copy to this thread, which issues whichever is ready, two deep.
-  std::thread dl_thread;
-  std::mutex dl_mu;
-  std::condition_variable dl_cv, dl_issued_cv;
-  std::deque<DlItem> dl_queue;
-  bool dl_stop = false;
-  int dl_busy = 0;  // items taken off the queue whose copies are being issued
-  hipStream_t dl_stream = nullptr;
-  std::string dl_error;
+  DlEngine *dl = nullptr;   // the device's download engine, once this context has handed it a copy
+  int dl_outstanding = 0;   // copies handed over and not issued yet (under dl->mu)
+  std::string dl_error;     // (under dl->mu)
 };
 
 namespace {
@@ -202,8 +213,8 @@ hipError_t build_ring(jb_ctx *ctx) {
 // that way) and has finished
 int slot_finish(jb_ctx *ctx, Slot &s) {
   if (s.dl_pending.load(std::memory_order_acquire)) {
-    std::unique_lock<std::mutex> lk(ctx->dl_mu);
-    ctx->dl_issued_cv.wait(lk, [&] { return s.dl_pending.load(std::memory_order_acquire) == 0; });
+    std::unique_lock<std::mutex> lk(ctx->dl->mu);
+    ctx->dl->issued_cv.wait(lk, [&] { return s.dl_pending.load(std::memory_order_acquire) == 0; });
     if (!ctx->dl_error.empty()) return fail(ctx, JB_ERR_HIP, "%s", ctx->dl_error.c_str());
   }
   JB_HIP(ctx, hipEventSynchronize(s.done));
@@ -221,22 +232,29 @@ int take_slot(jb_ctx *ctx, Slot **out) {
   return JB_OK;
 }
 
-void dl_thread_main(jb_ctx *ctx) {
-  (void)hipSetDevice(ctx->device);
-  std::deque<hipEvent_t> inflight;  // `done` events of the copies issued and not known to have finished
+std::mutex g_dl_mu;
+std::map<int, DlEngine *> g_dl;  // device -> its download engine, while any context holds it
+
+void dl_thread_main(DlEngine *eng) {
+  (void)hipSetDevice(eng->device);
+  // two copies deep, by the engine's OWN events (a context -- and its slots' events -- may be destroyed as soon as
+  // its copies have finished, while this thread still remembers them)
+  hipEvent_t mark[2] = {nullptr, nullptr};
+  bool marked[2] = {false, false};
+  for (hipEvent_t &m : mark) (void)hipEventCreateWithFlags(&m, hipEventDisableTiming);
+  unsigned n_issued = 0;
   for (;;) {
     DlItem it;
     bool have = false;
     {
-      std::unique_lock<std::mutex> lk(ctx->dl_mu);
-      ctx->dl_cv.wait(lk, [&] { return ctx->dl_stop || !ctx->dl_queue.empty(); });
-      if (ctx->dl_stop && ctx->dl_queue.empty()) return;
-      for (auto q = ctx->dl_queue.begin(); q != ctx->dl_queue.end(); ++q) {
+      std::unique_lock<std::mutex> lk(eng->mu);
+      eng->cv.wait(lk, [&] { return eng->stop || !eng->queue.empty(); });
+      if (eng->stop && eng->queue.empty()) break;
+      for (auto q = eng->queue.begin(); q != eng->queue.end(); ++q) {
         const hipError_t e = hipEventQuery(q->slot->computed);
         if (e != hipErrorNotReady) {  // finished (or failed: the copy below will say so)
           it = *q;
-          ctx->dl_queue.erase(q);
-          ctx->dl_busy++;
+          eng->queue.erase(q);
           have = true;
           break;
         }
@@ -248,43 +266,88 @@ void dl_thread_main(jb_ctx *ctx) {
       continue;
     }
     // two copies deep: the engine always has the next one, and nothing queues up behind a slow host
-    while (inflight.size() >= 2) {
-      (void)hipEventSynchronize(inflight.front());
-      inflight.pop_front();
-    }
+    const unsigned m = n_issued++ & 1;
+    if (marked[m]) (void)hipEventSynchronize(mark[m]);  // the copy before the last has finished
     hipError_t e;
-    if (it.rows) e = hipMemcpy2DAsync(it.dst, it.dst_pitch, it.src, it.src_pitch, it.row_bytes, it.rows, hipMemcpyDeviceToHost, ctx->dl_stream);
-    else e = hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, ctx->dl_stream);
-    if (e == hipSuccess && it.status_bytes) e = hipMemcpyAsync(it.status_dst, it.status_src, it.status_bytes, hipMemcpyDeviceToHost, ctx->dl_stream);
-    if (e == hipSuccess) e = hipEventRecord(it.slot->done, ctx->dl_stream);
-    inflight.push_back(it.slot->done);
+    if (it.rows) e = hipMemcpy2DAsync(it.dst, it.dst_pitch, it.src, it.src_pitch, it.row_bytes, it.rows, hipMemcpyDeviceToHost, eng->stream);
+    else e = hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, eng->stream);
+    if (e == hipSuccess && it.status_bytes) e = hipMemcpyAsync(it.status_dst, it.status_src, it.status_bytes, hipMemcpyDeviceToHost, eng->stream);
+    if (e == hipSuccess) e = hipEventRecord(it.slot->done, eng->stream);
+    marked[m] = mark[m] && hipEventRecord(mark[m], eng->stream) == hipSuccess;
     {
-      std::lock_guard<std::mutex> lk(ctx->dl_mu);
-      if (e != hipSuccess && ctx->dl_error.empty()) ctx->dl_error = std::string("download thread: ") + hipGetErrorString(e);
+      std::lock_guard<std::mutex> lk(eng->mu);
+      if (e != hipSuccess && it.ctx->dl_error.empty()) it.ctx->dl_error = std::string("download thread: ") + hipGetErrorString(e);
       it.slot->dl_pending.store(0, std::memory_order_release);
-      ctx->dl_busy--;
+      it.ctx->dl_outstanding--;
     }
-    ctx->dl_issued_cv.notify_all();
+    eng->issued_cv.notify_all();
   }
+  for (hipEvent_t m : mark)
+    if (m) (void)hipEventDestroy(m);
 }
 
-// hand a download to the download thread (started on first use); the caller has recorded item.slot->computed
+// hand a download to the device's download thread (engine and thread are made on first use); the caller has
+// recorded item.slot->computed and holds a DeviceGuard on ctx->device
 int dl_enqueue(jb_ctx *ctx, const DlItem &item) {
-  if (!ctx->dl_stream) JB_HIP(ctx, hipStreamCreateWithFlags(&ctx->dl_stream, hipStreamNonBlocking));
+  if (!ctx->dl) {
+    std::lock_guard<std::mutex> g(g_dl_mu);
+    DlEngine *&eng = g_dl[ctx->device];
+    if (!eng) {
+      std::unique_ptr<DlEngine> fresh(new DlEngine());
+      fresh->device = ctx->device;
+      JB_HIP(ctx, hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking));
+      fresh->thread = std::thread(dl_thread_main, fresh.get());
+      eng = fresh.release();
+    }
+    eng->refs++;
+    ctx->dl = eng;
+  }
   item.slot->dl_pending.store(1, std::memory_order_release);
   {
-    std::lock_guard<std::mutex> lk(ctx->dl_mu);
-    if (!ctx->dl_thread.joinable()) ctx->dl_thread = std::thread(dl_thread_main, ctx);
-    ctx->dl_queue.push_back(item);
+    std::lock_guard<std::mutex> lk(ctx->dl->mu);
+    ctx->dl_outstanding++;
+    ctx->dl->queue.push_back(item);
   }
-  ctx->dl_cv.notify_one();
+  ctx->dl->cv.notify_one();
   return JB_OK;
 }
 
-// every download handed over has been issued
+// every download this context handed over has been issued
 void dl_drain(jb_ctx *ctx) {
-  std::unique_lock<std::mutex> lk(ctx->dl_mu);
-  ctx->dl_issued_cv.wait(lk, [&] { return ctx->dl_queue.empty() && ctx->dl_busy == 0; });
+  if (!ctx->dl) return;
+  std::unique_lock<std::mutex> lk(ctx->dl->mu);
+  ctx->dl->issued_cv.wait(lk, [&] { return ctx->dl_outstanding == 0; });
+}
+
+// ... and has finished: the slots' `done` events (the engine's stream also carries other contexts' copies)
+hipError_t dl_wait_copies(jb_ctx *ctx) {
+  dl_drain(ctx);
+  for (int i = 0; i < ctx->n_slots; i++)
+    if (ctx->slots[i].done) {
+      const hipError_t e = hipEventSynchronize(ctx->slots[i].done);
+      if (e != hipSuccess) return e;
+    }
+  return hipSuccess;
+}
+
+// the context lets go of the device's engine; the last one out stops the thread
+void dl_release(jb_ctx *ctx) {
+  if (!ctx->dl) return;
+  (void)dl_wait_copies(ctx);
+  DlEngine *eng = ctx->dl;
+  ctx->dl = nullptr;
+  std::lock_guard<std::mutex> g(g_dl_mu);
+  if (--eng->refs > 0) return;
+  g_dl.erase(eng->device);
+  {
+    std::lock_guard<std::mutex> lk(eng->mu);
+    eng->stop = true;
+  }
+  eng->cv.notify_all();
+  eng->thread.join();
+  (void)hipStreamSynchronize(eng->stream);
+  (void)hipStreamDestroy(eng->stream);
+  delete eng;
 }
 
 int check_desc(jb_ctx *ctx, const jb_image_desc *d, jb_geometry *g) {
@@ -350,19 +413,7 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
 void jb_ctx_destroy(jb_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
-  if (ctx->dl_thread.joinable()) {
-    {
-      std::lock_guard<std::mutex> lk(ctx->dl_mu);
-      ctx->dl_stop = true;
-    }
-    ctx->dl_cv.notify_all();
-    ctx->dl_thread.join();
-  }
-  if (ctx->dl_stream) {
-    (void)hipStreamSynchronize(ctx->dl_stream);
-    (void)hipStreamDestroy(ctx->dl_stream);
-    ctx->dl_stream = nullptr;
-  }
+  dl_release(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   for (hipStream_t &ps : ctx->pool)
@@ -410,8 +461,7 @@ void *jb_ctx_stream(jb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int jb_ctx_synchronize(jb_ctx *ctx) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_ctx_synchronize: ctx is NULL");
   DeviceGuard guard(ctx->device);
-  dl_drain(ctx);
-  if (ctx->dl_stream) JB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
+  JB_HIP(ctx, dl_wait_copies(ctx));
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
@@ -493,8 +543,7 @@ int jb_ctx_reserve(jb_ctx *ctx, size_t max_coef_bytes, size_t max_rgb_bytes) {
   if (ctx->n_slots > 0 && max_coef_bytes <= ctx->max_coef && max_rgb_bytes <= ctx->max_rgb) return JB_OK;
   DeviceGuard guard(ctx->device);
   // nothing may be in flight while the slots' buffers are replaced
-  dl_drain(ctx);
-  if (ctx->dl_stream) JB_HIP(ctx, hipStreamSynchronize(ctx->dl_stream));
+  JB_HIP(ctx, dl_wait_copies(ctx));
   JB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream2) JB_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   for (hipStream_t ps : ctx->pool)
@@ -824,6 +873,7 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     // 5,767-6,567, 64 8192x8192 files 227-238 -> 262: profiles/r03/ab_download_thread.txt)
     JB_HIP(ctx, hipEventRecord(s.computed, up));
     DlItem it;
+    it.ctx = ctx;
     it.slot = &s;
     it.dst = rgb, it.src = s.d_rgb, it.bytes = rgb_total;
     it.rows = 0, it.dst_pitch = it.src_pitch = it.row_bytes = 0;

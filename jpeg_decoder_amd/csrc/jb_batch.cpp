@@ -243,6 +243,7 @@ struct Shared {
 struct Totals {
   std::mutex mu;
   double t_entropy = 0, t_device = 0, t_read = 0;
+  double first_submit = 1e30, last_submit = 0, first_back = 1e30, first_thread_done = 1e30;  // JPEGBLK_TIMING=3
   int first_error = JB_OK;
   std::string first_error_text;
 };
@@ -327,6 +328,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   const bool use_arena = r.arena && r.arena->base;
   const bool to_device = use_arena && r.arena->on_device;
   double t_entropy = 0, t_wait = 0, t_read = 0;
+  double first_submit = 1e30, last_submit = 0, first_back = 1e30;  // (JPEGBLK_TIMING=3)
   // the rest of a file whose head was parsed in pass 1
   auto load = [&](Parsed &p, int i) {
     if (p.loaded || p.status != JB_OK) return;
@@ -420,6 +422,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       report(i, st_j, text_j);
     }
     t_wait += now_s() - a;
+    if (first_back > 1e29) first_back = now_s();
     g.n = 0;
   };
   auto same_geometry = [](const Parsed &a, const Parsed &b) {
@@ -429,6 +432,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   };
   const int n_mine = (int)parsed.size();
   int k = 0, slot = 0;
+  int dev_groups = 0;  // device-entropy groups this thread has submitted
   while (k < n_mine) {
     Parsed &head = parsed[(size_t)k];
     load(head, index_of(k));
@@ -456,6 +460,10 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     size_t droom_c = r.dev_cap_coef / coef_bytes, droom_p = (use_arena ? r.dev_cap_rgb : lane->cap_rgb) / rgb_bytes;
     int room_dev = (int)(droom_c < droom_p ? droom_c : droom_p);
     if (room_dev > dev_max_group) room_dev = dev_max_group;
+    // The thread's first two device groups are a quarter and a half of the full size: the device and the link get
+    // their first work after two images' worth of host time instead of eight, which is what a batch whose share
+    // per thread is about one group (128 1080p files on 16 threads) otherwise waits for before anything overlaps.
+    if (dev_groups < 2) room_dev = room_dev >> (2 - dev_groups);
     if (room_dev < 1) room_dev = 1;
     // entropy-decode consecutive images of the head's geometry into the slot, back to back -- or,
     // for files with restart intervals, only ready them for the device decoder
@@ -560,6 +568,8 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       }
       if (st != JB_OK) text = jb_last_error(r.dev->ctx);
       t_wait += now_s() - a;
+      last_submit = now_s();
+      if (first_submit > 1e29) first_submit = last_submit;
     }
     if (st != JB_OK) {
       for (int j = 0; j < n; j++) report(index_of(k + j), st, text);
@@ -567,6 +577,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       grp[s].first = k;
       grp[s].n = n;
       grp[s].on_device = on_device;
+      if (on_device) dev_groups++;
       slot = (slot + 1) % kSlots;
     }
     k += n;
@@ -576,6 +587,11 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   r.tot->t_entropy += t_entropy;
   r.tot->t_device += t_wait;
   r.tot->t_read += t_read;
+  if (first_submit < r.tot->first_submit) r.tot->first_submit = first_submit;
+  if (last_submit > r.tot->last_submit) r.tot->last_submit = last_submit;
+  if (first_back < r.tot->first_back) r.tot->first_back = first_back;
+  const double done = now_s();
+  if (done < r.tot->first_thread_done) r.tot->first_thread_done = done;
 }
 
 }  // namespace
@@ -595,6 +611,33 @@ struct jb_batch_decoder {
     const int want = lane_slots(arena->base && arena->on_device), fit = lanes.empty() ? want : 64 / (int)lanes.size();
     return want < fit ? want : fit < 1 ? 1 : fit;
   }
+  // the caller's device region as it was given (jb_batch_decoder_set_device_output[s]); submit / collect
+  // split it between the two sides, run() uses all of it
+  uint8_t *region_base = nullptr;
+  size_t region_bytes = 0;
+  // how this decoder was made: its twin (submit / collect) is made the same way
+  std::vector<int> made_devices;
+  bool made_multi = false;
+  int made_threads = 0;
+  size_t made_coef = 0, made_rgb = 0;
+  // jb_batch_decoder_submit / _collect: up to two batches in flight, batch k on side k & 1 -- side 0 is this
+  // decoder, side 1 its twin (same devices, threads and sizes, its own ring, staging and arena) -- so that the
+  // start-up of one batch (headers, first groups) runs under the tail of the other (last kernels, last downloads)
+  struct Flight {
+    std::thread th;
+    bool busy = false;
+    int ticket = -1;
+    int rc = JB_OK;
+    std::string text;
+    double times[4] = {0, 0, 0, 0};
+    std::vector<std::string> path_text;  // the batch's paths, copied: the caller's array need not outlive submit
+    std::vector<const char *> path_ptr;
+  };
+  Flight flights[2];
+  int tickets = 0;
+  jb_batch_decoder *twin = nullptr;
+  bool split_for_sides = false;  // the outputs are arranged for submit / collect (twin arena, halves of the regions)
+  bool in_flight() const { return flights[0].busy || flights[1].busy; }
   // multi-device decoder (jb_batch_decoder_create_multi): one single-device decoder per listed
   // device; this object then only deals the files out and owns the shared arena
   std::vector<jb_batch_decoder *> parts;
@@ -739,7 +782,9 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
       if (ring_bytes > share * max_coef) ring_bytes = share * max_coef;
     }
   }
+  const double t_parsed = now_s();
   int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads, ring_bytes, ring_bytes) : JB_OK;
+  const double t_setup = now_s();
   if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
   // a device group is bounded by this run's group size (the ring slots may be larger: an earlier run's)
   const size_t group_cap = ring_bytes > max_coef ? ring_bytes : max_coef;
@@ -753,7 +798,13 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
       th.emplace_back([&, t] { decode_pass(r, &d->lanes[(size_t)t], t, parsed[(size_t)t], setup_rc, setup_text); });
     for (auto &x : th) x.join();
   }
+  const double t_joined = now_s();
   jb_ctx_synchronize(d->ctx);
+  if (d->knobs.timing == 3)
+    fprintf(stderr, "run_single %d files: headers %.2f ms, setup %.2f, first submit at %.2f, first group back at %.2f, last submit at %.2f, "
+            "first thread done at %.2f, all done at %.2f, synchronised at %.2f\n", n_paths, (t_parsed - t0) * 1e3, (t_setup - t_parsed) * 1e3,
+            (tot.first_submit - t0) * 1e3, (tot.first_back - t0) * 1e3, (tot.last_submit - t0) * 1e3, (tot.first_thread_done - t0) * 1e3,
+            (t_joined - t0) * 1e3, (now_s() - t0) * 1e3);
   if (times) {
     times[0] = now_s() - t0;
     times[1] = tot.t_entropy;
@@ -770,7 +821,14 @@ extern "C" int jb_batch_decoder_create(int device_id, int n_threads, size_t max_
                                        size_t max_rgb_bytes, jb_batch_decoder **out) {
   if (!out) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_create: out is NULL");
   *out = nullptr;
-  return create_single(device_id, clamp_threads(n_threads, jb_knobs_read()), max_coef_bytes, max_rgb_bytes, out);
+  int rc = create_single(device_id, clamp_threads(n_threads, jb_knobs_read()), max_coef_bytes, max_rgb_bytes, out);
+  if (rc == JB_OK) {
+    (*out)->made_devices.assign(1, device_id);
+    (*out)->made_threads = n_threads;
+    (*out)->made_coef = max_coef_bytes;
+    (*out)->made_rgb = max_rgb_bytes;
+  }
+  return rc;
 }
 
 extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_devices, int n_threads,
@@ -782,6 +840,11 @@ extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_device
   if (n_threads < n_devices) n_threads = n_devices;  // every device needs a host thread to feed it
   jb_batch_decoder *top = new jb_batch_decoder();
   top->device = device_ids[0];
+  top->made_devices.assign(device_ids, device_ids + n_devices);
+  top->made_multi = true;
+  top->made_threads = n_threads;
+  top->made_coef = max_coef_bytes;
+  top->made_rgb = max_rgb_bytes;
   for (int k = 0; k < n_devices; k++) {
     // host threads are dealt out evenly; the first (n_threads % n_devices) devices get one more
     const int share = n_threads / n_devices + (k < n_threads % n_devices ? 1 : 0);
@@ -801,6 +864,9 @@ extern "C" int jb_batch_decoder_create_multi(const int *device_ids, int n_device
 
 extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
   if (!d) return;
+  for (auto &f : d->flights)
+    if (f.th.joinable()) f.th.join();  // batches still in flight finish first (their results are dropped)
+  jb_batch_decoder_destroy(d->twin);
   for (jb_batch_decoder *p : d->parts) jb_batch_decoder_destroy(p);
   for (auto &l : d->lanes) l.release();
   jb_ctx_destroy(d->ctx);
@@ -811,6 +877,11 @@ extern "C" void jb_batch_decoder_destroy(jb_batch_decoder *d) {
 extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
   if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_arena: decoder is NULL");
   if (d->arena != &d->own_arena) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: set the arena on the multi-device decoder, not on one of its parts");
+  if (d->in_flight()) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: batches are in flight (collect them first)");
+  d->split_for_sides = false;  // the next submit arranges the two sides' outputs again
+  d->region_base = nullptr;
+  d->region_bytes = 0;
+  for (jb_batch_decoder *part : d->parts) part->region_base = nullptr, part->region_bytes = 0;
   if (d->own_arena.owned) jb_pinned_free(d->own_arena.base);
   d->own_arena.base = nullptr;
   d->own_arena.bytes = 0;
@@ -845,6 +916,7 @@ extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_b
     return jb_fail_(nullptr, JB_ERR_UNSUPPORTED, "jb_batch_decoder_set_device_output: a multi-device decoder takes one region per device (jb_batch_decoder_set_device_outputs)");
   if ((d_base == nullptr) != (bytes == 0)) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_set_device_output: pointer and size must both be given or both be zero");
   if ((uintptr_t)d_base & 255) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_output: the region must be 256-byte aligned");
+  if (d->in_flight()) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_device_output: batches are in flight (collect them first)");
   int rc = d_base ? jb_check_device_region_(d->device, d_base, bytes) : (int)JB_OK;
   if (rc != JB_OK) return rc;
   rc = jb_batch_decoder_set_arena(d, 0);  // releases a pinned arena, forgets an earlier device region
@@ -854,6 +926,8 @@ extern "C" int jb_batch_decoder_set_device_output(jb_batch_decoder *d, void *d_b
     d->own_arena.bytes = bytes;
     d->own_arena.on_device = true;
     d->own_arena.owned = false;
+    d->region_base = (uint8_t *)d_base;
+    d->region_bytes = bytes;
     for (auto &l : d->lanes) l.drop_out();  // no pixel staging: nothing is downloaded
   }
   return JB_OK;
@@ -866,6 +940,7 @@ extern "C" int jb_batch_decoder_set_device_outputs(jb_batch_decoder *d, void *co
     if (n != 1 || !d_bases || !bytes) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: a single-device decoder takes one region");
     return jb_batch_decoder_set_device_output(d, d_bases[0], bytes[0]);
   }
+  if (d->in_flight()) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_device_outputs: batches are in flight (collect them first)");
   const bool off = n == 0;
   if (!off && (n != (int)d->parts.size() || !d_bases || !bytes))
     return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_set_device_outputs: one region per listed device (or n = 0: host output again)");
@@ -885,6 +960,8 @@ extern "C" int jb_batch_decoder_set_device_outputs(jb_batch_decoder *d, void *co
     part->own_arena.used = 0;
     part->own_arena.on_device = !off;
     part->own_arena.owned = off;
+    part->region_base = part->own_arena.base;
+    part->region_bytes = part->own_arena.bytes;
     part->arena = off ? &d->own_arena : &part->own_arena;  // (host output: the parts share the top decoder's arena, if any)
     if (!off)
       for (auto &l : part->lanes) l.drop_out();
@@ -892,12 +969,54 @@ extern "C" int jb_batch_decoder_set_device_outputs(jb_batch_decoder *d, void *co
   return JB_OK;
 }
 
-extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *paths, int n_paths,
-                                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
-                                    double *times) {
-  if (!d || !paths || !rgb || !widths || !heights || !statuses)
-    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_run: NULL pointer");
-  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
+namespace {
+
+// the single-device decoders a decoder consists of
+std::vector<jb_batch_decoder *> singles_of(jb_batch_decoder *d) {
+  if (d->parts.empty()) return std::vector<jb_batch_decoder *>(1, d);
+  return d->parts;
+}
+
+// Where the pixels of the two sides go.  for_sides = false (jb_batch_decoder_run): this decoder has all of the
+// caller's device region(s).  for_sides = true (submit / collect): side 0 writes into the first half of every
+// region and the twin into the second; with a pinned arena (or none) the twin has one of the same size of its own.
+int arrange_outputs(jb_batch_decoder *d, bool for_sides) {
+  std::vector<jb_batch_decoder *> mine = singles_of(d), theirs;
+  if (d->twin) theirs = singles_of(d->twin);
+  bool any_region = false;
+  for (jb_batch_decoder *m : mine) any_region = any_region || m->region_base;
+  if (for_sides && d->twin) {
+    bool twin_on_device = false;
+    for (jb_batch_decoder *t : theirs) twin_on_device = twin_on_device || t->own_arena.on_device;
+    const size_t want = (!any_region && d->own_arena.base && d->own_arena.owned) ? d->own_arena.bytes : 0;
+    const size_t have = (d->twin->own_arena.base && d->twin->own_arena.owned) ? d->twin->own_arena.bytes : 0;
+    if (want != have || twin_on_device) {
+      int rc = jb_batch_decoder_set_arena(d->twin, want);
+      if (rc != JB_OK) return rc;
+    }
+  }
+  for (size_t k = 0; k < mine.size(); k++) {
+    jb_batch_decoder *m = mine[k];
+    if (!m->region_base) continue;
+    const size_t half = (m->region_bytes / 2) & ~(size_t)255;
+    m->own_arena.bytes = for_sides ? half : m->region_bytes;
+    if (for_sides && d->twin) {
+      jb_batch_decoder *t = theirs[k];
+      t->own_arena.base = m->region_base + half;
+      t->own_arena.bytes = half;
+      t->own_arena.used = 0;
+      t->own_arena.on_device = true;
+      t->own_arena.owned = false;
+      t->arena = &t->own_arena;
+      for (auto &l : t->lanes) l.drop_out();
+    }
+  }
+  d->split_for_sides = for_sides;
+  return JB_OK;
+}
+
+int run_impl(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8_t **rgb, int32_t *widths, int32_t *heights,
+             int *statuses, double *times) {
   if (d->parts.empty()) return run_single(d, paths, n_paths, rgb, widths, heights, statuses, times, d->arena == &d->own_arena);
   // multi-device: file i -> part i % n_parts (images are independent: nothing crosses devices);
   // every part runs its share on its own host threads, concurrently with the others
@@ -957,10 +1076,83 @@ extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *path
   return rc == JB_OK ? JB_OK : jb_fail_(nullptr, rc, text.c_str());
 }
 
+}  // namespace
+
+extern "C" int jb_batch_decoder_run(jb_batch_decoder *d, const char *const *paths, int n_paths,
+                                    uint8_t **rgb, int32_t *widths, int32_t *heights, int *statuses,
+                                    double *times) {
+  if (!d || !paths || !rgb || !widths || !heights || !statuses)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_run: NULL pointer");
+  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_run: negative count");
+  if (d->in_flight()) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_run: batches are in flight (collect them first)");
+  if (d->split_for_sides) {
+    int rc = arrange_outputs(d, false);
+    if (rc != JB_OK) return rc;
+  }
+  return run_impl(d, paths, n_paths, rgb, widths, heights, statuses, times);
+}
+
+extern "C" int jb_batch_decoder_submit(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8_t **rgb,
+                                       int32_t *widths, int32_t *heights, int *statuses, int *ticket) {
+  if (!d || !paths || !rgb || !widths || !heights || !statuses || !ticket)
+    return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_submit: NULL pointer");
+  if (n_paths < 0) return jb_fail_(nullptr, JB_ERR_GEOMETRY, "jb_batch_decoder_submit: negative count");
+  if (d->arena != &d->own_arena && d->parts.empty())
+    return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_submit: submit to the multi-device decoder, not to one of its parts");
+  for (int i = 0; i < n_paths; i++)
+    if (!paths[i]) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_submit: NULL path");
+  const int side = d->tickets & 1;
+  jb_batch_decoder::Flight &f = d->flights[side];
+  if (f.busy) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_submit: two batches are in flight: collect the older one first");
+  if (!d->twin) {
+    jb_batch_decoder *t = nullptr;
+    int rc = d->made_multi ? jb_batch_decoder_create_multi(d->made_devices.data(), (int)d->made_devices.size(), d->made_threads,
+                                                           d->made_coef, d->made_rgb, &t)
+                           : jb_batch_decoder_create(d->made_devices.empty() ? d->device : d->made_devices[0],
+                                                     d->made_threads > 0 ? d->made_threads : (int)d->lanes.size(), d->made_coef,
+                                                     d->made_rgb, &t);
+    if (rc != JB_OK) return rc;
+    d->twin = t;
+    d->split_for_sides = false;
+  }
+  if (!d->split_for_sides) {  // (only ever the case with nothing in flight: every call that clears it refuses otherwise)
+    int rc = arrange_outputs(d, true);
+    if (rc != JB_OK) return rc;
+  }
+  f.path_text.assign(paths, paths + n_paths);
+  f.path_ptr.resize((size_t)n_paths);
+  for (int i = 0; i < n_paths; i++) f.path_ptr[(size_t)i] = f.path_text[(size_t)i].c_str();
+  f.busy = true;
+  f.ticket = d->tickets++;
+  f.rc = JB_OK;
+  f.text.clear();
+  jb_batch_decoder *const target = side == 0 ? d : d->twin;
+  jb_batch_decoder::Flight *const fp = &f;
+  f.th = std::thread([=] {
+    fp->rc = run_impl(target, fp->path_ptr.data(), n_paths, rgb, widths, heights, statuses, fp->times);
+    if (fp->rc != JB_OK) fp->text = jb_last_error(nullptr);  // thread-local text: fetch it on this thread
+  });
+  *ticket = f.ticket;
+  return JB_OK;
+}
+
+extern "C" int jb_batch_decoder_collect(jb_batch_decoder *d, int ticket, double *times) {
+  if (!d) return jb_fail_(nullptr, JB_ERR_NULL, "jb_batch_decoder_collect: decoder is NULL");
+  jb_batch_decoder::Flight &f = d->flights[ticket & 1];
+  if (ticket < 0 || !f.busy || f.ticket != ticket)
+    return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_collect: no such batch in flight");
+  f.th.join();
+  f.busy = false;
+  if (times)
+    for (int j = 0; j < 4; j++) times[j] = f.times[j];
+  return f.rc == JB_OK ? JB_OK : jb_fail_(nullptr, f.rc, f.text.c_str());
+}
+
 extern "C" long long jb_batch_decoder_device_entropy_images(const jb_batch_decoder *d) {
   if (!d) return 0;
   long long n = d->ctx ? jb_ctx_device_entropy_images(d->ctx) : 0;
   for (const jb_batch_decoder *p : d->parts) n += jb_batch_decoder_device_entropy_images(p);
+  if (d->twin) n += jb_batch_decoder_device_entropy_images(d->twin);  // (the second side of submit / collect)
   return n;
 }
 

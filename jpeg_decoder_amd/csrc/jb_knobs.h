@@ -18,7 +18,7 @@
 //   JPEGBLK_NUMA          0: leave the host threads' CPU affinity alone; 1: bind them to the GPU's NUMA node even
 //                         under a CPU quota (default: bind only when the process owns a node's worth of CPUs)
 //   JPEGBLK_OVERSUBSCRIBE 1: allow more host threads than CPUs the process may use
-//   JPEGBLK_TIMING        1 | 2: where one decode(bytes) / one device-entropy submission spends its time, on stderr
+//   JPEGBLK_TIMING        1 | 2 | 3: where one decode(bytes) / one device-entropy submission / one batch run spends its time, on stderr
 //   JPEGBLK_HW_QUEUES     read when the LIBRARY IS LOADED (before HIP initialises, jb_api.cpp): hardware queues to
 //                         ask the runtime for (GPU_MAX_HW_QUEUES; default 16, 0 = leave the runtime's default)
 #pragma once
@@ -55,6 +55,6 @@ inline JbKnobs jb_knobs_read() {
   if (const char *e = getenv("JPEGBLK_DEV_GROUP_MB")) k.dev_group_mb = atol(e) < 0 ? 0 : atol(e);
   if (const char *e = getenv("JPEGBLK_NUMA")) k.numa = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1;
   k.oversubscribe = flag("JPEGBLK_OVERSUBSCRIBE");
-  if (const char *e = getenv("JPEGBLK_TIMING")) k.timing = e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0;
+  if (const char *e = getenv("JPEGBLK_TIMING")) k.timing = e[0] >= '1' && e[0] <= '3' ? e[0] - '0' : 0;
   return k;
 }

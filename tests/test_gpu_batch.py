@@ -352,3 +352,67 @@ def test_batch_decoder_device_resident_output(jb, oracle, tmp_path, monkeypatch,
         multi.set_device_outputs([])
         again, st2, _ = multi.run(paths)
         assert st2 == st_want and all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(again, want))
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+@pytest.mark.parametrize("output", ["malloc", "arena", "device"])
+def test_batch_decoder_submit_collect_stream(jb, oracle, tmp_path, monkeypatch, output, devices):
+    """jb_batch_decoder_submit / _collect: six batches of different files streamed through one decoder, two in
+    flight, every image against the oracle on the blocks written; the state rules (a third submit, run or
+    set_arena while batches are in flight, a ticket that does not exist) answer JB_ERR_STATE; then run() again
+    on the same decoder (all of a device region belongs to it again)."""
+    import torch
+    monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    pa, wa = _write_files(str(tmp_path), "a", 640, 360, 2, 2, 12, 3, 0, oracle)
+    pb, wb = _write_files(str(tmp_path), "b", 333, 211, 1, 1, 10, 2, 5, oracle)
+    pc, wc = _write_files(str(tmp_path), "c", 679, 451, 2, 1, 7, 2, 0, oracle)
+    batches = [(pa, wa), (pb, wb), (pc + pa[:3], wc + wa[:3]), (pb[:1], wb[:1]), (pa + pb, wa + wb), ([], [])]
+    per_batch = max(sum((w.size + 255) // 256 * 256 for w in want) for _, want in batches)
+    n_regions = len(devices) if devices else 1
+    regions = [torch.zeros(2 * per_batch + 512, dtype=torch.uint8, device="cuda:0") for _ in range(n_regions)]
+
+    def pixels(result, want):
+        if output != "device":
+            imgs, st, tm = result
+            _check(imgs, st, tm, want)
+            return
+        ptrs, dims, st, tm = result
+        torch.cuda.synchronize()
+        assert tm["rc"] == 0 and all(s == 0 for s in st), (tm, st)
+        for i, w in enumerate(want):
+            r = [g for g in regions if g.data_ptr() <= ptrs[i] < g.data_ptr() + g.numel()]
+            assert len(r) == 1, i
+            off = ptrs[i] - r[0].data_ptr()
+            got = r[0][off:off + w.size].cpu().numpy().reshape(w.shape)
+            assert dims[i] == (w.shape[1], w.shape[0]) and np.array_equal(got, w), i
+
+    with jb.BatchDecoder(4, 0, arena_bytes=per_batch if output == "arena" else 0, devices=devices) as dec:
+        if output == "device":
+            if devices:
+                dec.set_device_outputs([(g.data_ptr(), g.numel()) for g in regions])
+            else:
+                dec.set_device_output(regions[0].data_ptr(), regions[0].numel())
+        t0 = dec.submit(batches[0][0])
+        t1 = dec.submit(batches[1][0])
+        with pytest.raises(jb.JbError) as e:
+            dec.submit(batches[2][0])            # two in flight already
+        assert e.value.status == -7
+        assert jb.lib().jb_batch_decoder_set_arena(dec._h, 1 << 20) == -7
+        bad = dict(t0)
+        bad["id"] = type(t0["id"])(t0["id"].value + 6)
+        assert jb.lib().jb_batch_decoder_collect(dec._h, bad["id"], None) == -7
+        pixels(dec.collect(t0), batches[0][1])
+        flight = [t1]
+        for k in range(2, len(batches)):
+            flight.append(dec.submit(batches[k][0]))      # batch k starts while batch k-1 runs
+            pixels(dec.collect(flight.pop(0)), batches[k - 1][1])
+        pixels(dec.collect(flight.pop(0)), batches[-1][1])
+        assert jb.lib().jb_batch_decoder_collect(dec._h, t1["id"], None) == -7   # collected already
+        assert dec.device_entropy_images > 0
+        # the plain run on the same decoder afterwards
+        if output == "device":
+            pixels(dec.run_to_device(batches[4][0]), batches[4][1])
+        else:
+            pixels(dec.run(batches[4][0]), batches[4][1])
+        # a batch still in flight when the decoder is destroyed finishes first
+        dec.submit(batches[0][0])

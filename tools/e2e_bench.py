@@ -124,6 +124,56 @@ def device_output_run(jb, paths, want, threads, device, g0, args, w, h, world):
             "n_gpus": world, "pixels_checked": n, "entropy_on_device": bool(on_device)}
 
 
+def stream_run(jb, paths, want, threads, device, g0, args, arena):
+    """The same files as batches of args.stream: through run() one batch after the other, and through
+    submit / collect with two batches in flight (the start-up of one under the tail of the other)."""
+    import time
+    B = args.stream
+    batches = [paths[i:i + B] for i in range(0, len(paths), B)]
+    per = (g0.rgb_bytes + 255) // 256 * 256
+    bad = []
+    with jb.BatchDecoder(threads, device, g0.coef_bytes, g0.rgb_bytes, arena_bytes=B * per if arena else 0) as dec:
+        def check_for(b):
+            def check(i, view):
+                if not np.array_equal(view, want[b[i]]):
+                    bad.append(b[i])
+            return check
+        dec.run(paths[:threads], keep_pixels=False)
+        t = dec.submit(paths[:threads])            # builds the second side
+        dec.collect(t, keep_pixels=False)
+        t = dec.submit(paths[:threads])
+        t2 = dec.submit(paths[:threads])           # both sides once
+        dec.collect(t, keep_pixels=False)
+        dec.collect(t2, keep_pixels=False)
+        seq, stm = [], []
+        for k in range(args.repeat + 1):
+            time.sleep(0.1)
+            t0 = time.perf_counter()
+            for b in batches:
+                _, st, tm = dec.run(b, keep_pixels=False)
+                assert tm["rc"] == 0, tm
+            seq.append(time.perf_counter() - t0)
+            time.sleep(0.1)   # (an idle gap: tools/timeline.py separates the passes by it)
+            t0 = time.perf_counter()
+            flight = []
+            for b in batches:
+                flight.append((dec.submit(b), b))
+                if len(flight) == 2:
+                    tk, bb = flight.pop(0)
+                    _, st, tm = dec.collect(tk, keep_pixels=False, on_image=check_for(bb) if k == 0 else None)
+                    assert tm["rc"] == 0, tm
+            for tk, bb in flight:
+                _, st, tm = dec.collect(tk, keep_pixels=False, on_image=check_for(bb) if k == 0 else None)
+                assert tm["rc"] == 0, tm
+            stm.append(time.perf_counter() - t0)
+        assert not bad, f"stream: {len(bad)} images differ from the single-image decode"
+    n = len(paths)
+    # pass 0 is the checked one (the comparison runs inside the timed loop): not counted
+    return {"batch": B, "batches": len(batches), "one_after_the_other_images_per_s": round(n / min(seq[1:]), 1),
+            "two_in_flight_images_per_s": round(n / min(stm[1:]), 1), "walls_one_after_the_other": [round(x, 4) for x in seq],
+            "walls_two_in_flight": [round(x, 4) for x in stm], "pixels_checked": n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
@@ -138,6 +188,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=2, help="timed runs per configuration (the best is reported, all walls listed)")
     ap.add_argument("--no-pcie", action="store_true", help="skip part (2), so that the last device activity of the run is the last "
                     "timed batch (tools/timeline.py reads that burst out of a rocprofv3 trace)")
+    ap.add_argument("--stream", type=int, default=0, help="also stream the files as batches of this many through "
+                    "jb_batch_decoder_submit / _collect (two in flight), next to the same batches through run() one after the other")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
     from jpeg_decoder_amd.shard import rank_from_env
@@ -192,6 +244,9 @@ def main():
                 _, st, tm = min(runs, key=lambda x: x[2]["wall_s"])
                 walls = [round(x[2]["wall_s"], 3) for x in runs]
             assert all(s == 0 for s in st), st[:8]
+            stream = None
+            if args.stream > 0:
+                stream = stream_run(jb, paths, want, t, device, g0, args, mode == "arena")
             if dist is not None:   # whole job: all images / the slowest rank
                 import torch
                 tw = torch.tensor([tm["wall_s"]], dtype=torch.float64)
@@ -203,6 +258,8 @@ def main():
                         "wall_s": round(tm["wall_s"], 3), "walls": walls,
                         "device_busy_fraction": round(n_mine * k_ms * 1e-3 / tm["wall_s"], 4), "n_gpus": world,
                         "pixels_checked": n_mine, "entropy_on_device": bool(on_device)})
+            if stream:
+                res[-1]["stream"] = stream
         out["decode_path"] = res
         if world > 1:
             if rank == 0:
