@@ -410,10 +410,11 @@ class BatchDecoder:
         out = []
         for i in range(n):
             if rgb[i]:
-                m = w[i] * h[i] * 3
-                view = np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).reshape(h[i], w[i], 3)
-                if on_image is not None:
-                    on_image(i, view)
+                if on_image is not None or keep_pixels:
+                    m = w[i] * h[i] * 3
+                    view = np.ctypeslib.as_array(ctypes.cast(rgb[i], ctypes.POINTER(ctypes.c_uint8)), shape=(m,)).reshape(h[i], w[i], 3)
+                    if on_image is not None:
+                        on_image(i, view)
                 out.append(view.copy() if keep_pixels else (w[i], h[i]))
                 if not self._arena:
                     lib().jb_free(rgb[i])

@@ -79,6 +79,7 @@ struct Slot {
 // one download handed to the device's download thread
 struct DlItem {
   jb_ctx *ctx;
+  uint64_t age;  // the context's dl_age when the copy was handed over: the engine serves the smallest first
   Slot *slot;
   void *dst;
   const void *src;
@@ -145,6 +146,11 @@ struct jb_ctx {
   std::string error;
   DlEngine *dl = nullptr;   // the device's download engine, once this context has handed it a copy
   int dl_outstanding = 0;   // copies handed over and not issued yet (under dl->mu)
+  // Which of several contexts' ready copies the engine issues first: the smaller number.  The batch decoder gives
+  // every run the next number, so that of two batches in flight the OLDER one gets the link and finishes, instead of
+  // both sharing it and finishing together (two batches that share evenly fall into step, and the start-up of the
+  // next pair then overlaps nothing).
+  std::atomic<uint64_t> dl_age{0};
   std::string dl_error;     // (under dl->mu)
 };
 
@@ -250,14 +256,17 @@ void dl_thread_main(DlEngine *eng) {
       std::unique_lock<std::mutex> lk(eng->mu);
       eng->cv.wait(lk, [&] { return eng->stop || !eng->queue.empty(); });
       if (eng->stop && eng->queue.empty()) break;
+      // the oldest batch's ready copy; within a batch, the one handed over first
+      auto best = eng->queue.end();
       for (auto q = eng->queue.begin(); q != eng->queue.end(); ++q) {
+        if (best != eng->queue.end() && q->age >= best->age) continue;
         const hipError_t e = hipEventQuery(q->slot->computed);
-        if (e != hipErrorNotReady) {  // finished (or failed: the copy below will say so)
-          it = *q;
-          eng->queue.erase(q);
-          have = true;
-          break;
-        }
+        if (e != hipErrorNotReady) best = q;  // finished (or failed: the copy below will say so)
+      }
+      if (best != eng->queue.end()) {
+        it = *best;
+        eng->queue.erase(best);
+        have = true;
       }
       (void)hipGetLastError();  // (hipErrorNotReady is not an error of this thread's next call)
     }
@@ -452,6 +461,11 @@ void jb_ctx_destroy(jb_ctx *ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
+}
+
+// (jb_batch.cpp) the rank of this context's downloads among those of the other contexts on its device
+void jb_ctx_set_download_age_(jb_ctx *ctx, uint64_t age) {
+  if (ctx) ctx->dl_age.store(age, std::memory_order_relaxed);
 }
 
 const char *jb_last_error(const jb_ctx *ctx) { return ctx ? ctx->error.c_str() : g_tls_error.c_str(); }
@@ -874,6 +888,7 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     JB_HIP(ctx, hipEventRecord(s.computed, up));
     DlItem it;
     it.ctx = ctx;
+    it.age = ctx->dl_age.load(std::memory_order_relaxed);
     it.slot = &s;
     it.dst = rgb, it.src = s.d_rgb, it.bytes = rgb_total;
     it.rows = 0, it.dst_pitch = it.src_pitch = it.row_bytes = 0;

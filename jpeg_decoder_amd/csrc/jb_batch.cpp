@@ -46,6 +46,7 @@ void *jb_wait_begin_(jb_ctx *ctx, int ticket);
 int jb_wait_block_(jb_ctx *ctx, void *event);
 // binds the calling thread to the CPUs of the NUMA node closest to a device (jb_api.cpp)
 int jb_bind_thread_near_device_(int device, int numa_knob);
+extern "C" void jb_ctx_set_download_age_(jb_ctx *ctx, uint64_t age);
 // JB_OK when [p, p + bytes) is device memory of `device` (jb_api.cpp)
 int jb_check_device_region_(int device, const void *p, size_t bytes);
 
@@ -792,6 +793,11 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   r.dev_cap_rgb = (ring_bytes && group_cap < d->ctx_rgb) ? group_cap : d->ctx_rgb;
   // pass 2: entropy decoding on the host threads, all submitting to the shared context
   dev.ctx = d->ctx;
+  {
+    // of two batches in flight on one device (submit / collect, or two decoders) the older one's downloads go first
+    static std::atomic<uint64_t> run_seq{0};
+    jb_ctx_set_download_age_(d->ctx, ++run_seq);
+  }
   {
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; t++)
