@@ -141,6 +141,7 @@ struct jb_ctx {
   Slot huff_aux;   // blob + status of jb_entropy_decode_device (the only fields of it in use)
   int next_slot = 0;
   int next_ticket = 1;
+  int n_cus = 256;                 // compute units of the device
   long long n_device_entropy = 0;  // images whose entropy stage ran on the device (jb_huff.hip)
   jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
@@ -408,6 +409,11 @@ int jb_ctx_create(int device_id, size_t max_coef_bytes, size_t max_rgb_bytes, in
   ctx->knobs = jb_knobs_read();
   DeviceGuard guard(device_id);
   hipError_t e = hipSuccess;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->n_cus = cus;
+    (void)hipGetLastError();
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess && ctx->n_slots > 0) e = build_ring(ctx);
   if (e != hipSuccess) {
@@ -487,6 +493,12 @@ int jb_ctx_synchronize(jb_ctx *ctx) {
   return JB_OK;
 }
 
+// 4:4:4 launches of fewer than this many 192-lane workgroups per CU take the small-grid kernel when
+// JPEGBLK_SMALL_GRID is unset.  Measured on one box, cold, events around every launch, the two kernels interleaved
+// (profiles/r03/probe_small_grid.json): one 1080p image (507 workgroups) 12.0 -> 10.2 us, two (1,014) 14.5 -> 13.5,
+// four (2,028) 21.5 -> 20.6, one 1280x720 9.5 -> 8.5, one 640x360 9.4 -> 7.1, one 4096x4096 (4,096) 33.5 = 33.6.
+constexpr int kSmallGridBelowPerCu = 8;
+
 int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream) {
   if (!ctx) return fail(nullptr, JB_ERR_NULL, "jb_blocks_to_rgb_device: ctx is NULL");
   if (!b || !b->d_coef || !b->d_qtabs || !b->d_rgb) return fail(ctx, JB_ERR_NULL, "jb_blocks_to_rgb_device: NULL pointer");
@@ -528,6 +540,23 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   const int64_t n_tiles = (int64_t)b->n_images * tiles_per_image;
   if (n_tiles > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "batch too large for one launch (%lld tiles)", (long long)n_tiles);
   p.n_tiles = (int32_t)n_tiles;
+  // Small 4:4:4 launches (a single 1080p image is 507 workgroups on 256 CUs): four times as many one-wave workgroups
+  // (jb_kernels.hip jb_small_kernel_444), row-bound.  JPEGBLK_SMALL_GRID = 1 / 0 forces / forbids it; so does
+  // JPEGBLK_ROW_TILING=1 (that knob asks for the 192-lane kernel's row-bound instantiation).
+  if (b->desc.hs == 1 && b->desc.vs == 1 && !force_row &&
+      (ctx->knobs.small_grid == 1 || (ctx->knobs.small_grid < 0 && n_tiles < (int64_t)kSmallGridBelowPerCu * ctx->n_cus))) {
+    const int per = jbk_small_mcus();
+    p.tiles_per_row = (g.mcus_x + per - 1) / per;
+    const int64_t small_tiles = (int64_t)b->n_images * g.mcus_y * p.tiles_per_row;
+    if (small_tiles <= 0x7fffffffLL) {
+      p.linear = 0;
+      p.small_grid = 1;
+      p.tiles_per_image = (int32_t)((int64_t)g.mcus_y * p.tiles_per_row);
+      p.n_tiles = (int32_t)small_tiles;
+    } else {
+      p.tiles_per_row = (g.mcus_x + per_tile - 1) / per_tile;
+    }
+  }
   // 12-byte stores at any byte address: gfx950 under ROCm runs with unaligned global/buffer access
   // enabled, and odd widths with tightly packed rows (row stride 3*W) are the common case --
   // measured 1.67x faster than byte stores on 679x451 (tests/test_gpu_parity.py covers both).

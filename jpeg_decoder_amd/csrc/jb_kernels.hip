@@ -605,6 +605,127 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
   }
 }
 
+// ---- small grids (4:4:4): one WAVE per 16 MCUs -------------------------------------------------------------
+// A single 1080p 4:4:4 image is 507 tiles of the kernel above on 256 CUs: every CU runs its two workgroups through
+// load -> IDCT -> colour in step, and the launch is bounded by the length of that chain, not by traffic (DESIGN.md
+// section 5.2).  This variant cuts the same work into four times as many independent pieces: a 64-lane workgroup
+// owns 16 MCUs of one MCU row -- lanes 0-15 their Y blocks, 16-31 Cb, 32-47 Cr, 48-63 idle -- with the
+// quantisation tables in LDS (per-lane component), 6 KiB of strips, and no barrier other workgroups wait on, so
+// the phases of the eight or so waves on a CU interleave.  Arithmetic and its order are those of the kernel above.
+// Selected by the host for launches of fewer than 3 workgroups per CU (jb_api.cpp; JPEGBLK_SMALL_GRID).
+constexpr int kSmallMcus = 16;
+__global__ __launch_bounds__(64) void jb_small_kernel_444(const JbLaunch p) {
+  constexpr int kStrip = 2048 + 64;  // 4 rows x 128 samples x 4 B, skewed so the three strips start in different banks
+  constexpr int kQPitch = 64 + 4;    // dwords per table in LDS (the three tables start in different banks)
+  __shared__ __attribute__((aligned(16))) char lds[3 * kStrip + 3 * kQPitch * 4];
+  int32_t *const qlds = (int32_t *)(lds + 3 * kStrip);
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int img = tile / p.tiles_per_image;
+  const int rem = tile - img * p.tiles_per_image;
+  const int my = rem / p.tiles_per_row;
+  const int mx0 = (rem - my * p.tiles_per_row) * kSmallMcus;
+  const int nvalid = min(kSmallMcus, p.mcus_x - mx0);
+  const int comp = min(lane >> 4, 2);  // (lanes 48-63 repeat the Cr lanes' work and write nothing)
+  const bool active = lane < 48;
+  const int m = lane & 15;
+  const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride + ((int64_t)my * p.mcus_x + mx0) * 384;
+  const int32_t *qsrc = (const int32_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
+#pragma unroll
+  for (int i = 0; i < 3; i++) qlds[i * kQPitch + lane] = qsrc[i * 64 + lane];
+  float v[64];
+  {
+    uint32_t raw[32];
+    const u32x4_t *src = (const u32x4_t *)(tile_coef + (uint32_t)(min(m, nvalid - 1) * 3 + comp) * 128u);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32x4_t t = src[j];
+      raw[j * 4 + 0] = t.x, raw[j * 4 + 1] = t.y, raw[j * 4 + 2] = t.z, raw[j * 4 + 3] = t.w;
+    }
+    __syncthreads();  // the tables are in LDS
+    const int32_t *q = qlds + comp * kQPitch;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const int4 q4 = *(const int4 *)(q + k * 8 + i);
+        const int qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t w = raw[k * 4 + ((i + e) >> 1)];
+          const int c = ((i + e) & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+          v[k * 8 + i + e] = (float)__mul24(c, qq[e]);  // jpeg.cpp:563-569
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
+    aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i], v[6 * 8 + i], v[7 * 8 + i]);
+#pragma unroll
+  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
+    aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+
+  // colour stage, rows 0-3 then rows 4-7 of the MCU row: strips of 4 rows x 128 samples per component, 16-B chunk c
+  // of a row stored at c ^ ((c >> 3) & 1) (as above); then one lane = 4 adjacent pixels, a wave-iteration = 2 rows
+  const int sw = (m >> 2) & 1;
+  char *const dst = lds + comp * kStrip + m * 32;
+  const int x4 = lane & 31;
+  const int rd = (x4 ^ ((x4 >> 3) & 1)) * 16;
+  uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  const int x = mx0 * 8 + x4 * 4;                 // image column of this lane's first pixel
+  const int npx = min(4, min(nvalid * 8, p.width - mx0 * 8) - x4 * 4);  // its pixels inside the image (<= 0: none)
+#pragma unroll
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = phase * 4 + kk;
+        *(float4 *)(dst + kk * 512 + sw * 16) = make_float4(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3]);
+        *(float4 *)(dst + kk * 512 + (sw ^ 1) * 16) = make_float4(v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int r = it * 2 + (lane >> 5);
+      const int y = my * 8 + phase * 4 + r;
+      const float4 Y = *(const float4 *)(lds + r * 512 + rd);
+      const float4 B = *(const float4 *)(lds + kStrip + r * 512 + rd);
+      const float4 R = *(const float4 *)(lds + 2 * kStrip + r * 512 + rd);
+      const float yy[4] = {Y.x, Y.y, Y.z, Y.w}, cb[4] = {B.x, B.y, B.z, B.w}, cr[4] = {R.x, R.y, R.z, R.w};
+      float rr[4], gg[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // jpeg.cpp:521-535
+        rr[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+        gg[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+        bb[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+      }
+      if (p.fast_store) {
+        uint32_t w0, w1, w2;
+        pack12_rtz(rr, gg, bb, w0, w1, w2);
+        if (y < p.height && npx == 4) {
+          // a wave-uniform descriptor at the first of the iteration's two rows; the lane adds its row and column
+          uint8_t *const rows = img_rgb + (int64_t)(my * 8 + phase * 4 + it * 2) * p.rgb_row_stride + (int64_t)mx0 * 24;
+          const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, 0x7ffffff0, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, (lane >> 5) * (int)p.rgb_row_stride + x4 * 12, 0, JB_STORE_AUX);
+        }
+      }
+      uint8_t *const o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+      if (y < p.height && npx > 0 && (!p.fast_store || npx < 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i < npx) {
+            o[i * 3 + 0] = (uint8_t)pack_u8(rr[i], 0, 0);
+            o[i * 3 + 1] = (uint8_t)pack_u8(gg[i], 0, 0);
+            o[i * 3 + 2] = (uint8_t)pack_u8(bb[i], 0, 0);
+          }
+      }
+    }
+  }
+}
+
 template <int HS, int VS>
 static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   using LM = LaneMap<HS, VS>;
@@ -641,8 +762,16 @@ int jbk_linear_ok(int hs, int vs, int mcus_x) {
   return mcus_x >= 256 / (8 * hs);
 }
 
+int jbk_small_mcus() { return kSmallMcus; }
+
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
+  if (p.small_grid) {  // (the host only sets it for 4:4:4, with the tile counts of this tiling)
+    if (hs != 1 || vs != 1) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(jb_small_kernel_444, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    return hipGetLastError();
+  }
   if (hs == 1 && vs == 1) return launch_t<1, 1>(p, stream);
   if (hs == 2 && vs == 1) return launch_t<2, 1>(p, stream);
   if (hs == 1 && vs == 2) return launch_t<1, 2>(p, stream);

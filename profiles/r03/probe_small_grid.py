@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""the REAL kernel on a small grid.  jb_small_kernel_444 (one wave per 16 MCUs; JPEGBLK_SMALL_GRID=1)
+against jb_tile_kernel<1,1> (192 lanes per 64 MCUs; =0) on launches that do not fill the device: HIP events around
+every launch, cold buffer sets (> 512 MiB rotating), the two contexts interleaved round by round on one box."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import bench
+    import jpeg_decoder_amd as jb
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(dev)
+    ctxs = {}
+    for knob in ("0", "1"):
+        os.environ["JPEGBLK_SMALL_GRID"] = knob
+        ctxs[knob] = jb.Context(0)
+    os.environ.pop("JPEGBLK_SMALL_GRID")
+
+    def timed(ctx, res, launches):
+        nb = len(res.batches)
+        for k in range(40):
+            ctx.blocks_to_rgb_device(res.batches[k % nb], stream.cuda_stream)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for k in range(launches):
+            evs[k][0].record(stream)
+            ctx.blocks_to_rgb_device(res.batches[k % nb], stream.cuda_stream)
+            evs[k][1].record(stream)
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) * 1e3 for a, b in evs]
+
+    out = {}
+    with torch.cuda.stream(stream):
+        for wl, n, sets in [("1920x1080-444", 1, 32), ("1920x1080-444", 2, 16), ("1920x1080-444", 4, 8), ("1280x720-444", 1, 64),
+                            ("640x360-444", 1, 64), ("4096x4096-444", 1, 4)]:
+            res = bench.Resident(jb, torch, dev, wl, n, sets, seed=1)
+            us = {"0": [], "1": []}
+            for rnd in range(4):
+                for knob in ("0", "1"):
+                    us[knob] += timed(ctxs[knob], res, 200)
+            g = res.g
+            tiles_default = n * ((g.mcus_x * g.mcus_y + 63) // 64)
+            tiles_small = n * g.mcus_y * ((g.mcus_x + 15) // 16)
+            row = {"workgroups_default": tiles_default, "workgroups_small": tiles_small, "algorithmic_bytes": res.alg_bytes}
+            for knob, name in (("0", "jb_tile_kernel<1,1>"), ("1", "jb_small_kernel_444")):
+                med = float(np.median(us[knob]))
+                row[name] = {"us_median": round(med, 2), "us_min": round(float(np.min(us[knob])), 2), "us_mean": round(float(np.mean(us[knob])), 2),
+                             "GB_s": round(res.alg_bytes / med / 1e3, 1)}
+            out[f"{wl} x{n}"] = row
+            print(f"{wl} x{n}", json.dumps(row), flush=True)
+            del res
+            torch.cuda.empty_cache()
+    for c in ctxs.values():
+        c.close()
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "probe_small_grid.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -606,3 +606,55 @@ def test_reference_with_the_integration_patch(tmp_path, name):
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     _, _, _, want = load_golden(name)
     assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), want)
+
+
+@pytest.mark.parametrize("byte_store", [False, True])
+def test_small_grid_444_kernel_vs_oracle(jb, oracle, monkeypatch, byte_store):
+    """jb_small_kernel_444 (JPEGBLK_SMALL_GRID=1: one wave per 16 MCUs, the variant for launches that do not fill the
+    device) against the oracle: sizes whose last tile of a row is ragged (1..15 MCUs), odd widths with tight rows and
+    padded, misaligned rows, one pixel, a batch of images with per-image tables, 16-bit table entries, and the
+    1080p frame of BASELINE.json's config 2 -- with guard bytes around every image, both store paths.  The same
+    inputs through the default kernel must give the same bytes (JPEGBLK_SMALL_GRID=0)."""
+    import torch
+    from jpeg_decoder_amd import synth
+    from jpeg_decoder_amd.api import torch_batch
+    from oracle.pyoracle import make_desc as odesc
+    if byte_store:
+        monkeypatch.setenv("JPEGBLK_BYTE_STORE", "1")
+    else:
+        monkeypatch.delenv("JPEGBLK_BYTE_STORE", raising=False)
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(dev)
+    cases = [(1, 1, 0, 0, 1), (8, 8, 0, 1, 1), (127, 9, 2, 1, 3), (128, 16, 0, 0, 2), (129, 17, 1, 3, 1), (333, 41, 0, 1, 2),
+             (679, 451, 0, 3, 1), (1921, 37, 5, 2, 1), (1920, 1080, 0, 0, 1), (2048, 24, 0, 0, 4)]
+    for (w, h, pad, off, n) in cases:
+        desc = jb.make_desc(w, h, 1, 1)
+        stride = 3 * w + pad
+        per = h * stride + 32
+        coefs, qs, wants = [], [], []
+        for i in range(n):
+            coef, q = synth.synth_blocks(w, h, 1, 1, 40 + i)
+            if i == 1:
+                q = (q.astype(np.int64) * 97 % 4000 + 1).astype(q.dtype)   # another table per image, entries above 255
+            coefs.append(coef), qs.append(jb.resolve_qtabs(desc, q))
+            wants.append(oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q, nthreads=8))
+        results = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("JPEGBLK_SMALL_GRID", knob)
+            with torch.cuda.stream(ts), jb.Context(0) as ctx:
+                coef_t = torch.from_numpy(np.stack(coefs)).to(dev)
+                q_t = torch.from_numpy(np.stack(qs)).to(dev)
+                raw = torch.full((n * per + 16,), 0xC5, dtype=torch.uint8, device=dev)
+                view = raw[off:off + n * per].view(n, per)[:, :h * stride].view(n, h, stride)
+                b = torch_batch(desc, n, coef_t, q_t, view, shared_qtabs=False)
+                ctx.blocks_to_rgb_device(b, ts.cuda_stream)
+                torch.cuda.synchronize()
+            results[knob] = raw.cpu().numpy()
+        host = results["1"]
+        assert np.array_equal(host, results["0"]), (w, h, "small-grid and default kernels differ")
+        assert (host[:off] == 0xC5).all()
+        for i in range(n):
+            img = host[off + i * per: off + (i + 1) * per]
+            rows = img[:h * stride].reshape(h, stride)
+            assert np.array_equal(rows[:, :3 * w].reshape(h, w, 3), wants[i]), (w, h, i, byte_store)
+            assert (rows[:, 3 * w:] == 0xC5).all() and (img[h * stride:] == 0xC5).all(), (w, h, i)
