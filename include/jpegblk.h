@@ -54,6 +54,8 @@
  *   JPEGBLK_DEV_GROUP_MB   MB of coefficients per group whose entropy stage runs on the device (96)
  *   JPEGBLK_NUMA           0 = leave the host threads' CPU affinity alone, 1 = always bind them to the GPU's node
  *   JPEGBLK_OVERSUBSCRIBE  1 = allow more host threads than CPUs the process may use
+ *   JPEGBLK_STAGED_STORE   1 = (measurement builds of the kernels only, tools/build_variant.sh; the product ignores it) the
+ *                          staged, line-aligned store stage for every image that takes the linear tiling
  *   JPEGBLK_SMALL_GRID     4:4:4 launches: 1 = always the one-wave-per-16-MCUs kernel, 0 = never (default: launches of
  *                          fewer than 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images)
  *   JPEGBLK_TIMING         1 | 2 | 3 = where one decode(bytes) / one device-entropy submission / one batch run spends its time (stderr)

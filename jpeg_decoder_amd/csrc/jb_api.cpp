@@ -562,6 +562,9 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   // measured 1.67x faster than byte stores on 679x451 (tests/test_gpu_parity.py covers both).
   // JPEGBLK_BYTE_STORE=1 forces the byte-store path (test / A-B knob).
   p.fast_store = ctx->knobs.byte_store ? 0 : 1;
+  // (measurement builds of jb_kernels.hip only -- tools/build_variant.sh -DJB_LAB: the staged store stage of the linear
+  // tiling; the product's kernels ignore the field)
+  p.staged = (p.linear && p.fast_store && !p.small_grid && ctx->knobs.staged_store == 1) ? 1 : 0;
   p.chroma_q_equal = (b->desc.qtab_id[1] == b->desc.qtab_id[2]) ? 1 : 0;
   DeviceGuard guard(ctx->device);
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;

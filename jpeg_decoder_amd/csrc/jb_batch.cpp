@@ -272,7 +272,10 @@ struct Run {
 // of a 200 ms batch during which the device had nothing to do, and held every file in memory at once.
 // A head that does not parse cleanly (headers longer than the head, progressive and multi-scan files,
 // errors) is settled on the whole file, so every status is the one the whole file gives.
-constexpr size_t kHeadBytes = (size_t)64 << 10;
+// (Two head sizes: the headers of a plain baseline file end within a few hundred bytes, and reading 4 KB instead of
+// 64 KB takes pass 1 of 1,024 files on 16 threads from 3.6-4.0 ms to about 1 ms; files with large APPn segments --
+// EXIF, ICC profiles -- get the 64 KB, then the whole file.)
+constexpr size_t kHeadBytes[2] = {(size_t)4 << 10, (size_t)64 << 10};
 
 void parse_one(Parsed &p) {
   p.status = jb_entropy_decode(p.bytes.data(), p.bytes.size(), &p.desc, p.qtabs, nullptr, 0);
@@ -285,18 +288,15 @@ void parse_pass(const Run &r, int t, std::vector<Parsed> &parsed, size_t *max_co
   for (size_t k = 0; k < parsed.size(); k++) {
     const int i = (*r.lists)[(size_t)t][k];
     Parsed &p = parsed[k];
-    double a = now_s();
-    bool ok = read_prefix(r.paths[i], kHeadBytes, p.bytes, &p.loaded);
-    if (ok) {
+    bool ok = true;
+    p.status = JB_ERR_FORMAT;
+    p.loaded = false;
+    for (int level = 0; level < 3 && ok && p.status != JB_OK && !p.loaded; level++) {  // heads, then the whole file decides
+      const double a = now_s();
+      ok = level < 2 ? read_prefix(r.paths[i], kHeadBytes[level], p.bytes, &p.loaded) : read_file(r.paths[i], p.bytes);
       *t_read += now_s() - a;
-      parse_one(p);
-      if (p.status != JB_OK && !p.loaded) {  // not settled by the head: the whole file decides
-        a = now_s();
-        ok = read_file(r.paths[i], p.bytes);
-        *t_read += now_s() - a;
-        p.loaded = ok;
-        if (ok) parse_one(p);
-      }
+      if (level == 2) p.loaded = ok;
+      if (ok) parse_one(p);
     }
     if (!ok) {
       p.status = JB_ERR_FORMAT;

@@ -22,6 +22,7 @@ struct JbLaunch {
   int32_t fast_store;         // 1: 12-byte stores (any byte alignment); 0: byte stores (JPEGBLK_BYTE_STORE=1)
   int32_t chroma_q_equal;     // 1 when Cb and Cr use the same table (desc.qtab_id[1] == qtab_id[2])
   int32_t reserved;           // 0 (777 = skip switch of the timing-experiment builds)
+  int32_t staged;             // 1 (linear tiling only): the line-aligned store stage for rows that are not 64-byte aligned
   int32_t small_grid;         // 1: 4:4:4 only, one 64-lane workgroup per jbk_small_mcus() MCUs of an MCU row (row-bound)
 };
 

@@ -206,6 +206,7 @@ __device__ __forceinline__ void pack12_rtz(const float (&r)[4], const float (&g)
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32x4_t u32x4_u __attribute__((aligned(1)));  // 16 bytes at any byte address
 
 
 // Measurement variants (tools/ablate.sh through tools/build_variant.sh -DJB_LAB -DJB_EXP_NO_...): a stage is
@@ -259,10 +260,18 @@ struct LaneMap {
 // same table, the usual case).  MIXQ = true: a wave may hold blocks of two components with
 // different tables and selects per lane; kept out of the MIXQ = false instantiation because its
 // register pressure would cost the common case a wave per SIMD.
-template <int HS, int VS, bool MIXQ, bool LINEAR>
+// STAGED = true (linear tiling only): the colour stage packs the pixels back into LDS and the same wave then writes
+// the strip row as whole 64-byte lines plus byte runs at its two ends, instead of one 12-byte store per lane at
+// whatever alignment the row has (see "staged" below).  A MEASURED VARIANT, not a product path: it is only
+// instantiated in -DJB_LAB builds (tools/build_variant.sh; JPEGBLK_STAGED_STORE=1 selects it there).  On the sizes
+// it was meant for it is 1-3 % slower than the stores it replaces, and 4-10 % slower on aligned rows
+// (profiles/r03/probe_staged.json): the aligned lines are worth about 5 %, the second trip
+// through LDS and the serial pack-then-copy of a row per wave cost more.
+template <int HS, int VS, bool MIXQ, bool LINEAR, bool STAGED = false>
 // (5 waves/SIMD are asked for where that costs no spill: 4:4:4 and 4:4:0; forcing it on 4:2:0 or
 // 4:2:2 spills and measured 9 % slower)
 __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_tile_kernel(const JbLaunch p) {
+  static_assert(!STAGED || LINEAR, "the staged store stage is an instantiation of the linear tiling");
   using LM = LaneMap<HS, VS>;
   constexpr int kTileBlocks = LM::TB;
   constexpr int kStripBytes = kTileBlocks * 128;  // half of the tile's f32 samples: 24 or 32 KiB
@@ -482,6 +491,79 @@ __global__ __launch_bounds__(tile_blocks(HS, VS), (HS == 1) ? 5 : 1) void jb_til
     }
     lds_barrier();
 
+    if constexpr (STAGED) {
+      // ---- staged: pack into LDS, then write line-aligned ----
+      // Pass A.  One wave takes a whole strip row, segment after segment: the 12 packed bytes of a lane go back
+      // into the row's own luma strip at segment * 768 + lane * 12 -- at or below every byte the wave has still to
+      // read, and no other wave touches this row -- so the row ends up as npixels * 3 contiguous output bytes.
+      constexpr int IPR = TASKS_PER_ROW / 64;
+      for (int row = wave; row < YROWS; row += kTileBlocks / 64) {
+        char *const rowp = lds + row * (YW * 4);
+#pragma unroll
+        for (int seg = 0; seg < IPR; seg++) {
+          const float4 Y = *(const float4 *)(rowp + lane_y_off + seg * 1024);
+          float cb[4], cr[4];
+          const int coff = (row / VS) * (CW * 4) + seg * (1024 / HS);
+          if (HS == 1) {
+            const float4 a = *(const float4 *)(lds + CB_OFF + lane_c_off + coff);
+            const float4 b = *(const float4 *)(lds + CR_OFF + lane_c_off + coff);
+            cb[0] = a.x, cb[1] = a.y, cb[2] = a.z, cb[3] = a.w;
+            cr[0] = b.x, cr[1] = b.y, cr[2] = b.z, cr[3] = b.w;
+          } else {
+            const float2 a = *(const float2 *)(lds + CB_OFF + lane_c_off + coff);
+            const float2 b = *(const float2 *)(lds + CR_OFF + lane_c_off + coff);
+            cb[0] = cb[1] = a.x, cb[2] = cb[3] = a.y;
+            cr[0] = cr[1] = b.x, cr[2] = cr[3] = b.y;
+          }
+          const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+          float r[4], g[4], b[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            r[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+            g[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+            b[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+          }
+          uint32_t w0, w1, w2;
+          pack12_rtz(r, g, b, w0, w1, w2);
+          asm volatile("" ::: "memory");  // (the reads of this segment stay in front of its writes, the writes in front of the next reads)
+          uint32_t *const o = (uint32_t *)(rowp + seg * 768 + lane_late * 12);
+          o[0] = w0, o[1] = w1, o[2] = w2;
+          asm volatile("" ::: "memory");
+        }
+        // Pass B, by the same wave on the row it has just packed (so nothing but its own LDS traffic has to be waited
+        // for).  A strip row is the pixels of the tile's MCUs, which lie in one image row per MCU row the tile
+        // touches: each such piece is written as [bytes up to the first 64-byte line][whole 16-byte chunks from
+        // there][the last bytes], the chunks fetched from LDS at whatever byte offset that takes.  Whole lines
+        // wherever the piece covers them, whatever the row stride.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int y_in = phase * 4 + (row >> 2) * 8 + (row & 3);
+        int m = 0, my_k = my, mx_k = mx0;
+        while (m < nvalid) {
+          const int cnt = min(nvalid - m, p.mcus_x - mx_k);
+          const int y = my_k * 8 * VS + y_in, x0 = mx_k * 8 * HS;
+          const int len = min(cnt * 8 * HS, p.width - x0) * 3;   // bytes of the piece inside the image
+          if (y < p.height && len > 0) {
+            uint8_t *const dstp = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x0 * 3;
+            const int src = row * (YW * 4) + m * (8 * HS * 3);     // LDS byte offset of the piece (a multiple of 8)
+            const int head = min(len, (int)((64 - ((uintptr_t)dstp & 63)) & 63));
+            const int nbody = (len - head) >> 4;
+            const int tail = len - head - nbody * 16;
+            if (lane_late < head) dstp[lane_late] = (uint8_t)lds[src + lane_late];
+            if (lane_late < tail) dstp[len - tail + lane_late] = (uint8_t)lds[src + len - tail + lane_late];
+            // (gfx950 reads 16 bytes of LDS at any byte address in one ds_read_b128: unaligned DS access is on under ROCm)
+            const char *const from = lds + src + head;
+            u32x4_t *const lines = (u32x4_t *)(dstp + head);
+            for (int c = lane_late; c < nbody; c += 64) {
+              const u32x4_t v4 = *(const u32x4_u *)(from + c * 16);
+              __builtin_nontemporal_store(v4, lines + c);
+            }
+          }
+          m += cnt;
+          mx_k = 0;
+          my_k++;
+        }
+      }
+    } else
     // colour transform + store: one lane = 4 adjacent pixels of one row, one wave-iteration =
     // 256 adjacent pixels (768 contiguous output bytes)
     // image row of strip row sr: block-row sr/4, row 4*phase + sr%4 within the block
@@ -742,6 +824,12 @@ static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   // unrelated earlier call (a failed attribute query, say) is not this launch's
   (void)hipGetLastError();
   constexpr unsigned extra_lds = 0;
+#if defined(JB_LAB)
+  if (kCanLinear && p.linear && p.staged) {
+    if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear, kCanLinear>), grid, block, extra_lds, stream, p);
+    else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear, kCanLinear>), grid, block, extra_lds, stream, p);
+  } else
+#endif
   if (kCanLinear && p.linear) {
     if (mixq) hipLaunchKernelGGL((jb_tile_kernel<HS, VS, true, kCanLinear>), grid, block, extra_lds, stream, p);
     else hipLaunchKernelGGL((jb_tile_kernel<HS, VS, false, kCanLinear>), grid, block, extra_lds, stream, p);

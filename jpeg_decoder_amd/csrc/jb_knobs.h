@@ -13,6 +13,8 @@
 //   JPEGBLK_BYTE_STORE    1: every pixel through byte stores (the path odd widths took before the 12-byte
 //                         stores at byte-aligned addresses; kept as the second implementation tests compare)
 //   JPEGBLK_ROW_TILING    1: the row-bound tiling for every image (default: the linear tiling where rows are ragged)
+//   JPEGBLK_STAGED_STORE  1: (measurement builds of jb_kernels.hip with -DJB_LAB only; the product ignores it) the staged,
+//                         line-aligned store stage for every image that takes the linear tiling
 //   JPEGBLK_SMALL_GRID    4:4:4 launches: 1 = always the one-wave-per-16-MCUs kernel, 0 = never (default: for launches
 //                         of fewer than 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images)
 //   JPEGBLK_GROUP_MB      MB of coefficients per group of small images decoded on the host threads (default 16; 0: one image per submission)
@@ -33,6 +35,7 @@ struct JbKnobs {
   bool byte_store = false;
   bool row_tiling = false;
   int small_grid = -1;       // -1: automatic
+  int staged_store = 0;
   long group_mb = -1;        // -1: the default
   long dev_group_mb = -1;
   int numa = -1;             // -1: automatic, 0: off, 1: forced
@@ -54,6 +57,7 @@ inline JbKnobs jb_knobs_read() {
   }
   k.byte_store = flag("JPEGBLK_BYTE_STORE");
   k.row_tiling = flag("JPEGBLK_ROW_TILING");
+  if (const char *e = getenv("JPEGBLK_STAGED_STORE")) k.staged_store = e[0] == '1' ? 1 : 0;
   if (const char *e = getenv("JPEGBLK_SMALL_GRID")) k.small_grid = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1;
   if (const char *e = getenv("JPEGBLK_GROUP_MB")) k.group_mb = atol(e) < 0 ? 0 : atol(e);
   if (const char *e = getenv("JPEGBLK_DEV_GROUP_MB")) k.dev_group_mb = atol(e) < 0 ? 0 : atol(e);

@@ -239,25 +239,31 @@ def test_device_batch_api_per_image_tables(jb, oracle):
 def test_unaligned_output_both_store_paths(jb, oracle, monkeypatch, hs, vs, byte_store):
     """rgb pointer / stride not multiples of 4 (odd widths with tightly packed rows are the common
     case): the default path stores 12 bytes per lane at byte-aligned addresses, JPEGBLK_BYTE_STORE=1
-    selects the byte-store path.  Both must be exact and must not touch a byte outside the rows."""
+    selects the byte-store path.  Both must be exact and must not touch a byte outside the rows.
+    (The staged, line-aligned store stage -- a measured variant that only exists in -DJB_LAB builds of the kernels --
+    went through this same test, 3 x 4 samplings green, before it was taken out of the product:
+    profiles/r03/staged_store_parity.txt; profiles/r03/probe_staged.py compares its bytes with the product path's.)"""
     import torch
     from jpeg_decoder_amd import synth
     from jpeg_decoder_amd.api import torch_batch
     from oracle.pyoracle import make_desc as odesc
-    if byte_store:
+    monkeypatch.setenv("JPEGBLK_SMALL_GRID", "0")      # (the 192-lane kernel's store paths are what this test is about)
+    if byte_store is True:
         monkeypatch.setenv("JPEGBLK_BYTE_STORE", "1")
     else:
         monkeypatch.delenv("JPEGBLK_BYTE_STORE", raising=False)
     dev = torch.device("cuda:0")
     ts = torch.cuda.Stream(dev)
-    for (w, h, pad, off) in [(333, 41, 2, 1), (679, 451, 0, 3), (1921, 37, 1, 2), (515, 16, 0, 1)]:
+    # (260 / 300 wide: a tile of 64 / 32 MCUs spans three MCU rows; 1024 wide with a 64-byte-aligned row: no byte runs at all)
+    for (w, h, pad, off) in [(333, 41, 2, 1), (679, 451, 0, 3), (1921, 37, 1, 2), (515, 16, 0, 1), (260, 50, 0, 5), (300, 70, 61, 63),
+                             (1040, 33, 16, 0)]:
         desc = jb.make_desc(w, h, hs, vs)
         coef, q = synth.synth_blocks(w, h, hs, vs, 9)
         stride = 3 * w + pad
         with torch.cuda.stream(ts), jb.Context(0) as ctx:
             coef_t = torch.from_numpy(coef).to(dev)
             q_t = torch.from_numpy(jb.resolve_qtabs(desc, q)).to(dev)
-            raw = torch.full((h * stride + 16,), 0xC5, dtype=torch.uint8, device=dev)
+            raw = torch.full((h * stride + 80,), 0xC5, dtype=torch.uint8, device=dev)
             view = raw[off:off + h * stride].view(1, h, stride)
             b = torch_batch(desc, 1, coef_t.view(1, -1, 64), q_t, view)
             ctx.blocks_to_rgb_device(b, ts.cuda_stream)
