@@ -142,6 +142,7 @@ struct jb_ctx {
   int next_slot = 0;
   int next_ticket = 1;
   int n_cus = 256;                 // compute units of the device
+  size_t blob_hint = 0;            // the largest device blob any slot has been given (huff_stage)
   long long n_device_entropy = 0;  // images whose entropy stage ran on the device (jb_huff.hip)
   jb_image_desc last_desc = {0, 0, 0, 0, {0, 0, 0}, 0};  // frame of the last jb_decode_file / jb_decode_memory
   std::string error;
@@ -206,6 +207,18 @@ hipError_t build_ring(jb_ctx *ctx) {
     // threads on a 16-CPU share: no difference, 6,003 vs 5,671 and 216 vs 217 images/s)
     if (e == hipSuccess && !s.done) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     if (e == hipSuccess && !s.computed) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
+    // what a submission decoded on the device needs beside the coefficients: status words, and a blob for the scan
+    // bytes and the decoder's per-chunk state -- about a seventh of the coefficient bytes for quality-75 files --
+    // made here, with the ring, rather than by the first submission that lands on the slot
+    if (e == hipSuccess && !s.h_status && ctx->knobs.gpu_huffman != 0) {
+      e = hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipMalloc((void **)&s.d_status, 4 * 256);
+    }
+    if (e == hipSuccess && !s.d_blob && ctx->knobs.gpu_huffman != 0 && ctx->n_slots > 1) {
+      const size_t cap = ctx->max_coef / 6 + ((size_t)256 << 10);
+      e = hipMalloc(&s.d_blob, cap);
+      if (e == hipSuccess) s.blob_cap = cap;
+    }
   }
   return e;
 }
@@ -778,11 +791,16 @@ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, size_t zero_bytes, int16_t *d_out, hipStream_t up,
                int sync_launches = kJbSyncLaunches) {
   if (lay.device_total > s.blob_cap || !s.d_blob) {  // (the slot is idle: its previous submission has been waited for)
+    // hipFree / hipMalloc stall the whole device: a slot that has to grow takes the largest size any slot of this
+    // context has needed, so that a ring of 64 slots stops growing after the first full-size groups instead of
+    // once per slot (which kept the first five or six runs of a fresh decoder slower than the rest)
     if (s.d_blob) (void)hipFree(s.d_blob);
     s.d_blob = nullptr, s.blob_cap = 0;
-    const size_t cap = lay.device_total + lay.device_total / 4 + 65536;
+    size_t cap = lay.device_total + lay.device_total / 4 + 65536;
+    if (cap < ctx->blob_hint) cap = ctx->blob_hint;
     JB_HIP(ctx, hipMalloc(&s.d_blob, cap));
     s.blob_cap = cap;
+    ctx->blob_hint = cap;
   }
   if (!s.h_status) {
     JB_HIP(ctx, hipHostMalloc((void **)&s.h_status, 4 * 256, hipHostMallocDefault));

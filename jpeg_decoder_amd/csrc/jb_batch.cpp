@@ -146,11 +146,15 @@ struct Lane {
   uint8_t *blob[kMaxSlots] = {};     // pinned: a device-entropy group packed for upload (jb_huff_pack_)
   size_t blob_cap[kMaxSlots] = {};
   int device_of_blobs = 0;
-  uint8_t *ensure_blob(int device, int s, size_t need) {
+  // `need` bytes now; `full` = what a group of the full size would need by this group's bytes per image (the first
+  // groups of a thread are smaller: a blob sized for one of them would be re-pinned, milliseconds, when a full group
+  // comes to the slot)
+  uint8_t *ensure_blob(int device, int s, size_t need, size_t full) {
     if (need <= blob_cap[s]) return blob[s];
     jb_pinned_free(blob[s]);
     blob_cap[s] = 0;
-    const size_t cap = need + need / 4 + 65536;
+    if (full < need) full = need;
+    const size_t cap = full + full / 4 + 65536;
     blob[s] = (uint8_t *)jb_pinned_alloc_on(device, cap);
     if (blob[s]) blob_cap[s] = cap;
     return blob[s];
@@ -461,6 +465,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     size_t droom_c = r.dev_cap_coef / coef_bytes, droom_p = (use_arena ? r.dev_cap_rgb : lane->cap_rgb) / rgb_bytes;
     int room_dev = (int)(droom_c < droom_p ? droom_c : droom_p);
     if (room_dev > dev_max_group) room_dev = dev_max_group;
+    const int room_dev_full = room_dev < 1 ? 1 : room_dev;
     // The thread's first two device groups are a quarter and a half of the full size: the device and the link get
     // their first work after two images' worth of host time instead of eight, which is what a batch whose share
     // per thread is about one group (128 1080p files on 16 threads) otherwise waits for before anything overlaps.
@@ -546,7 +551,8 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     if (st == JB_OK && on_device) {  // pack the group into this thread's pinned blob -- outside the shared lock
       std::vector<const JbHuffJob *> ptrs;
       for (auto &j : jobs) ptrs.push_back(j.get());
-      uint8_t *blob = lane->ensure_blob(r.device, s, jb_huff_pack_size_(ptrs.data(), n));
+      const size_t blob_bytes = jb_huff_pack_size_(ptrs.data(), n);
+      uint8_t *blob = lane->ensure_blob(r.device, s, blob_bytes, blob_bytes / (size_t)n * (size_t)room_dev_full);
       if (!blob) {
         st = JB_ERR_HIP;
         text = "pinned host allocation failed";
