@@ -32,8 +32,14 @@ def main():
     ts = torch.cuda.Stream(dev)
     edges = [1, 7, 8, 9, 15, 16, 17, 255, 256, 257, 511, 512, 513, 767, 768, 1023, 1024, 1025, 1535, 1536, 1537, 1920, 2047, 2048]
     t0, n, pixels = time.time(), 0, 0
-    with torch.cuda.stream(ts), jb.Context(0) as ctx:
+    # two contexts (knobs are read when a context is made): the default -- 4:4:4 launches of this size take the
+    # one-wave-per-16-MCUs kernel -- and one that keeps every launch on the 192-lane kernel
+    os.environ["JPEGBLK_SMALL_GRID"] = "0"
+    big_only = jb.Context(0)
+    os.environ.pop("JPEGBLK_SMALL_GRID")
+    with torch.cuda.stream(ts), jb.Context(0) as default_ctx, big_only:
         while time.time() - t0 < args.seconds:
+            ctx = default_ctx if rng.random() < 0.5 else big_only
             hs, vs = [(1, 1), (2, 1), (1, 2), (2, 2)][rng.integers(4)]
             w = int(rng.choice(edges) + rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(1, 2200))
             h = int(rng.choice(edges[:16]) + rng.integers(-3, 4)) if rng.random() < 0.3 else int(rng.integers(1, 700))
