@@ -556,7 +556,7 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   // Small 4:4:4 launches (a single 1080p image is 507 workgroups on 256 CUs): four times as many one-wave workgroups
   // (jb_kernels.hip jb_small_kernel_444), row-bound.  JPEGBLK_SMALL_GRID = 1 / 0 forces / forbids it; so does
   // JPEGBLK_ROW_TILING=1 (that knob asks for the 192-lane kernel's row-bound instantiation).
-  if (b->desc.hs == 1 && b->desc.vs == 1 && !force_row &&
+  if (b->desc.hs == 1 && b->desc.vs == 1 && !force_row && b->rgb_row_stride < (1LL << 30) &&  // (the lane's row offset is 32-bit)
       (ctx->knobs.small_grid == 1 || (ctx->knobs.small_grid < 0 && n_tiles < (int64_t)kSmallGridBelowPerCu * ctx->n_cus))) {
     const int per = jbk_small_mcus();
     p.tiles_per_row = (g.mcus_x + per - 1) / per;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -891,6 +892,7 @@ extern "C" int jb_batch_decoder_set_arena(jb_batch_decoder *d, size_t bytes) {
   if (d->arena != &d->own_arena) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: set the arena on the multi-device decoder, not on one of its parts");
   if (d->in_flight()) return jb_fail_(nullptr, JB_ERR_STATE, "jb_batch_decoder_set_arena: batches are in flight (collect them first)");
   d->split_for_sides = false;  // the next submit arranges the two sides' outputs again
+  if (d->twin) (void)jb_batch_decoder_set_arena(d->twin, 0);  // (its arena or region halves go as well; the next submit gives it new ones)
   d->region_base = nullptr;
   d->region_bytes = 0;
   for (jb_batch_decoder *part : d->parts) part->region_base = nullptr, part->region_bytes = 0;
@@ -1140,10 +1142,16 @@ extern "C" int jb_batch_decoder_submit(jb_batch_decoder *d, const char *const *p
   f.text.clear();
   jb_batch_decoder *const target = side == 0 ? d : d->twin;
   jb_batch_decoder::Flight *const fp = &f;
-  f.th = std::thread([=] {
-    fp->rc = run_impl(target, fp->path_ptr.data(), n_paths, rgb, widths, heights, statuses, fp->times);
-    if (fp->rc != JB_OK) fp->text = jb_last_error(nullptr);  // thread-local text: fetch it on this thread
-  });
+  try {
+    f.th = std::thread([=] {
+      fp->rc = run_impl(target, fp->path_ptr.data(), n_paths, rgb, widths, heights, statuses, fp->times);
+      if (fp->rc != JB_OK) fp->text = jb_last_error(nullptr);  // thread-local text: fetch it on this thread
+    });
+  } catch (const std::exception &e) {  // no thread to be had: nothing is in flight
+    f.busy = false;
+    d->tickets--;
+    return jb_fail_(nullptr, JB_ERR_CAPACITY, "jb_batch_decoder_submit: cannot start a thread");
+  }
   *ticket = f.ticket;
   return JB_OK;
 }
