@@ -325,12 +325,14 @@ class Resident:
         self.alg_bytes = nimg * (g.n_coded_blocks * 128 + self.w * self.h * 3)  # 128 B/block in + 3 B/pixel out
         self.pixels = nimg * self.w * self.h
         self.kernel = jb.lib().jb_kernel_name(self.desc).decode()
-        # 4:4:4 launches of fewer than 8 workgroups per CU take the one-wave-per-16-MCUs kernel (csrc/jb_api.cpp
+        # 4:4:4 and 4:2:0 launches of up to 8 workgroups per CU take the one-wave kernels (csrc/jb_api.cpp
         # kSmallGridBelowPerCu; JPEGBLK_SMALL_GRID forces either)
-        tiles = nimg * ((g.mcus_x * g.mcus_y + 63) // 64)
+        per_tile = {(1, 1): 64, (2, 2): 32}.get((self.hs, self.vs))
         knob = os.environ.get("JPEGBLK_SMALL_GRID", "")[:1]
-        if (self.hs, self.vs) == (1, 1) and (knob == "1" or (knob != "0" and tiles < 8 * torch.cuda.get_device_properties(dev).multi_processor_count)):
-            self.kernel = "jb_small_kernel_444"
+        if per_tile:
+            tiles = nimg * ((g.mcus_x * g.mcus_y + per_tile - 1) // per_tile)
+            if knob == "1" or (knob != "0" and tiles <= 8 * torch.cuda.get_device_properties(dev).multi_processor_count):
+                self.kernel = "jb_small_kernel_444" if self.hs == 1 else "jb_small_kernel_420"
 
 
 def main():

@@ -56,8 +56,8 @@
  *   JPEGBLK_OVERSUBSCRIBE  1 = allow more host threads than CPUs the process may use
  *   JPEGBLK_STAGED_STORE   1 = (measurement builds of the kernels only, tools/build_variant.sh; the product ignores it) the
  *                          staged, line-aligned store stage for every image that takes the linear tiling
- *   JPEGBLK_SMALL_GRID     4:4:4 launches: 1 = always the one-wave-per-16-MCUs kernel, 0 = never (default: launches of
- *                          fewer than 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images)
+ *   JPEGBLK_SMALL_GRID     4:4:4 and 4:2:0 launches: 1 = always the one-wave kernels, 0 = never (default: launches of
+ *                          up to 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images, one 4096x4096 4:2:0)
  *   JPEGBLK_TIMING         1 | 2 | 3 = where one decode(bytes) / one device-entropy submission / one batch run spends its time (stderr)
  *   JPEGBLK_HW_QUEUES      read when the library is LOADED: hardware queues to ask the HIP runtime for
  *                          (GPU_MAX_HW_QUEUES; default 16, 0 = the runtime's default).  Process-wide, and only

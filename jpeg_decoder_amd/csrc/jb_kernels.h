@@ -23,13 +23,13 @@ struct JbLaunch {
   int32_t chroma_q_equal;     // 1 when Cb and Cr use the same table (desc.qtab_id[1] == qtab_id[2])
   int32_t reserved;           // 0 (777 = skip switch of the timing-experiment builds)
   int32_t staged;             // 1 (linear tiling only): the line-aligned store stage for rows that are not 64-byte aligned
-  int32_t small_grid;         // 1: 4:4:4 only, one 64-lane workgroup per jbk_small_mcus() MCUs of an MCU row (row-bound)
+  int32_t small_grid;         // 1: 4:4:4 and 4:2:0 only, one 64-lane workgroup per jbk_small_mcus() MCUs of an MCU row (row-bound)
 };
 
 // MCUs covered by one workgroup (a tile is always 192 coded blocks): 64 / 48 / 32.
 int jbk_mcus_per_tile(int hs, int vs);
-// MCUs per workgroup of the small-grid 4:4:4 kernel
-int jbk_small_mcus();
+// MCUs per workgroup of the small-grid kernels (4:4:4: 16, 4:2:0: 8; 0: the layout has none)
+int jbk_small_mcus(int hs, int vs);
 // Can the layout use the linear (MCU-stream) tiling for an image with mcus_x MCUs per row?
 int jbk_linear_ok(int hs, int vs, int mcus_x);
 // Launch the fused kernel for luma sampling (hs, vs): one 192-lane workgroup per tile.

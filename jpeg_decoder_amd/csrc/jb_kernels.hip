@@ -808,6 +808,135 @@ __global__ __launch_bounds__(64) void jb_small_kernel_444(const JbLaunch p) {
   }
 }
 
+// The same for 4:2:0: a 64-lane workgroup owns 8 MCUs of one MCU row -- lanes 0-31 their luma blocks (MCU l >> 2,
+// block l & 3 in decode order: top left, top right, bottom left, bottom right), 32-39 Cb, 40-47 Cr, 48-63 idle.
+// Strips per phase: 8 luma rows (rows 4p..4p+3 of both block rows) x 128 samples, 4 chroma rows (2p, 2p+1, 4+2p,
+// 5+2p: reference jpeg.cpp:518-520) x 64 samples per chroma component; a chroma lane picks those rows of its block
+// with a select per value (the 192-lane kernel permutes them in the column pass, which a wave of mixed lanes cannot).
+constexpr int kSmallMcus420 = 8;
+__global__ __launch_bounds__(64) void jb_small_kernel_420(const JbLaunch p) {
+  constexpr int kYStrip = 8 * 128 * 4;       // 4 KiB
+  constexpr int kCStrip = 4 * 64 * 4 + 64;   // 1 KiB, skewed
+  constexpr int kQPitch = 64 + 4;
+  __shared__ __attribute__((aligned(16))) char lds[kYStrip + 2 * kCStrip + 3 * kQPitch * 4];
+  int32_t *const qlds = (int32_t *)(lds + kYStrip + 2 * kCStrip);
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int img = tile / p.tiles_per_image;
+  const int rem = tile - img * p.tiles_per_image;
+  const int my = rem / p.tiles_per_row;
+  const int mx0 = (rem - my * p.tiles_per_row) * kSmallMcus420;
+  const int nvalid = min(kSmallMcus420, p.mcus_x - mx0);
+  const bool active = lane < 48;
+  const int comp = lane < 32 ? 0 : (lane < 40 ? 1 : 2);  // (lanes 48-63 repeat Cr lanes' work and write nothing)
+  const int m = lane < 32 ? lane >> 2 : (lane & 7);
+  const int slot = lane < 32 ? (lane & 3) : 4 + comp - 1;  // block of the MCU in decode order
+  const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride + ((int64_t)my * p.mcus_x + mx0) * 768;
+  const int32_t *qsrc = (const int32_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
+#pragma unroll
+  for (int i = 0; i < 3; i++) qlds[i * kQPitch + lane] = qsrc[i * 64 + lane];
+  float v[64];
+  {
+    uint32_t raw[32];
+    const u32x4_t *src = (const u32x4_t *)(tile_coef + (uint32_t)(min(m, nvalid - 1) * 6 + slot) * 128u);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32x4_t t = src[j];
+      raw[j * 4 + 0] = t.x, raw[j * 4 + 1] = t.y, raw[j * 4 + 2] = t.z, raw[j * 4 + 3] = t.w;
+    }
+    __syncthreads();  // the tables are in LDS
+    const int32_t *q = qlds + comp * kQPitch;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const int4 q4 = *(const int4 *)(q + k * 8 + i);
+        const int qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t w = raw[k * 4 + ((i + e) >> 1)];
+          const int c = ((i + e) & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+          v[k * 8 + i + e] = (float)__mul24(c, qq[e]);  // jpeg.cpp:563-569
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
+    aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i], v[6 * 8 + i], v[7 * 8 + i]);
+#pragma unroll
+  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
+    aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+
+  // where this lane's block lands: luma block (bv, bh) of MCU m in strip rows 4*bv.., 8-sample column 2*m + bh;
+  // a chroma block in its component's strip, column m.  16-B chunk c of a row is stored at c ^ ((c >> 3) & 1).
+  const bool luma = comp == 0;
+  const int bv = luma ? (slot >> 1) : 0, bh = luma ? (slot & 1) : 0;
+  const int col = luma ? m * 2 + bh : m;
+  const int sw = (col >> 2) & 1;
+  const int pitch = luma ? 512 : 256;
+  char *const dst = lds + (luma ? bv * 4 * 512 : kYStrip + (comp - 1) * kCStrip) + col * 32;
+  const int x4 = lane & 31;
+  const int rd_y = (x4 ^ ((x4 >> 3) & 1)) * 16;
+  const int rd_c = ((x4 >> 1) ^ ((x4 >> 4) & 1)) * 16 + (x4 & 1) * 8;  // chroma chunk x4 / 2, its half x4 & 1
+  uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  const int x = mx0 * 16 + x4 * 4;
+  const int npx = min(4, min(nvalid * 16, p.width - mx0 * 16) - x4 * 4);
+#pragma unroll
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int kl = phase * 4 + kk;                         // luma: rows 4p .. 4p+3 of the block
+        const int kc = phase * 2 + (kk & 1) + (kk >> 1) * 4;   // chroma: rows 2p, 2p+1, 4+2p, 5+2p
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = luma ? v[kl * 8 + e] : v[kc * 8 + e];
+        *(float4 *)(dst + kk * pitch + sw * 16) = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4 *)(dst + kk * pitch + (sw ^ 1) * 16) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 2 + (lane >> 5);                      // luma strip row
+      const int y = my * 16 + phase * 4 + (r >> 2) * 8 + (r & 3);
+      const float4 Y = *(const float4 *)(lds + r * 512 + rd_y);
+      const float2 B = *(const float2 *)(lds + kYStrip + (r >> 1) * 256 + rd_c);
+      const float2 R = *(const float2 *)(lds + kYStrip + kCStrip + (r >> 1) * 256 + rd_c);
+      const float yy[4] = {Y.x, Y.y, Y.z, Y.w}, cb[4] = {B.x, B.x, B.y, B.y}, cr[4] = {R.x, R.x, R.y, R.y};
+      float rr[4], gg[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // jpeg.cpp:521-535
+        rr[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+        gg[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+        bb[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+      }
+      if (p.fast_store) {
+        uint32_t w0, w1, w2;
+        pack12_rtz(rr, gg, bb, w0, w1, w2);
+        if (y < p.height && npx == 4) {
+          // a wave-uniform descriptor at row 0 of the MCU row; the lane adds its row and column
+          uint8_t *const rows = img_rgb + (int64_t)(my * 16) * p.rgb_row_stride + (int64_t)mx0 * 48;
+          const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, 0x7ffffff0, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, (y - my * 16) * (int)p.rgb_row_stride + x4 * 12, 0, JB_STORE_AUX);
+        }
+      }
+      uint8_t *const o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+      if (y < p.height && npx > 0 && (!p.fast_store || npx < 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i < npx) {
+            o[i * 3 + 0] = (uint8_t)pack_u8(rr[i], 0, 0);
+            o[i * 3 + 1] = (uint8_t)pack_u8(gg[i], 0, 0);
+            o[i * 3 + 2] = (uint8_t)pack_u8(bb[i], 0, 0);
+          }
+      }
+    }
+  }
+}
+
 template <int HS, int VS>
 static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   using LM = LaneMap<HS, VS>;
@@ -850,14 +979,15 @@ int jbk_linear_ok(int hs, int vs, int mcus_x) {
   return mcus_x >= 256 / (8 * hs);
 }
 
-int jbk_small_mcus() { return kSmallMcus; }
+int jbk_small_mcus(int hs, int vs) { return hs == 1 && vs == 1 ? kSmallMcus : hs == 2 && vs == 2 ? kSmallMcus420 : 0; }
 
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
-  if (p.small_grid) {  // (the host only sets it for 4:4:4, with the tile counts of this tiling)
-    if (hs != 1 || vs != 1) return hipErrorInvalidValue;
+  if (p.small_grid) {  // (the host only sets it for 4:4:4 and 4:2:0, with the tile counts of this tiling)
+    if (jbk_small_mcus(hs, vs) == 0) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(jb_small_kernel_444, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    if (hs == 1) hipLaunchKernelGGL(jb_small_kernel_444, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL(jb_small_kernel_420, dim3(p.n_tiles), dim3(64), 0, stream, p);
     return hipGetLastError();
   }
   if (hs == 1 && vs == 1) return launch_t<1, 1>(p, stream);

@@ -15,8 +15,8 @@
 //   JPEGBLK_ROW_TILING    1: the row-bound tiling for every image (default: the linear tiling where rows are ragged)
 //   JPEGBLK_STAGED_STORE  1: (measurement builds of jb_kernels.hip with -DJB_LAB only; the product ignores it) the staged,
 //                         line-aligned store stage for every image that takes the linear tiling
-//   JPEGBLK_SMALL_GRID    4:4:4 launches: 1 = always the one-wave-per-16-MCUs kernel, 0 = never (default: for launches
-//                         of fewer than 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images)
+//   JPEGBLK_SMALL_GRID    4:4:4 and 4:2:0 launches: 1 = always the one-wave kernels, 0 = never (default: for launches
+//                         of up to 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images, one 4096x4096 4:2:0)
 //   JPEGBLK_GROUP_MB      MB of coefficients per group of small images decoded on the host threads (default 16; 0: one image per submission)
 //   JPEGBLK_DEV_GROUP_MB  MB of coefficients per group whose entropy stage runs on the device (default 96)
 //   JPEGBLK_NUMA          0: leave the host threads' CPU affinity alone; 1: bind them to the GPU's NUMA node even

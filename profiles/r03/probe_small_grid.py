@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""the REAL kernel on a small grid.  jb_small_kernel_444 (one wave per 16 MCUs; JPEGBLK_SMALL_GRID=1)
-against jb_tile_kernel<1,1> (192 lanes per 64 MCUs; =0) on launches that do not fill the device: HIP events around
+"""the REAL kernel on a small grid.  jb_small_kernel_444 / _420 (one wave per 16 / 8 MCUs;
+JPEGBLK_SMALL_GRID=1) against jb_tile_kernel<1,1> / <2,2> (192 lanes per 64 / 32 MCUs; =0) on launches that do not fill the device: HIP events around
 every launch, cold buffer sets (> 512 MiB rotating), the two contexts interleaved round by round on one box."""
 import json
 import os
@@ -40,17 +40,21 @@ def main():
     out = {}
     with torch.cuda.stream(stream):
         for wl, n, sets in [("1920x1080-444", 1, 32), ("1920x1080-444", 2, 16), ("1920x1080-444", 4, 8), ("1280x720-444", 1, 64),
-                            ("640x360-444", 1, 64), ("4096x4096-444", 1, 4)]:
+                            ("640x360-444", 1, 64), ("4096x4096-444", 1, 4),
+                            ("640x360-420", 1, 64), ("1920x1080-420", 1, 64), ("1920x1080-420", 4, 16), ("1920x1080-420", 8, 8),
+                            ("4096x4096-420", 1, 8), ("4096x4096-420", 2, 4), ("4096x4096-420", 4, 2), ("4096x4096-420", 8, 1),
+                            ("1920x1080-420", 32, 2)]:
             res = bench.Resident(jb, torch, dev, wl, n, sets, seed=1)
             us = {"0": [], "1": []}
             for rnd in range(4):
                 for knob in ("0", "1"):
                     us[knob] += timed(ctxs[knob], res, 200)
             g = res.g
-            tiles_default = n * ((g.mcus_x * g.mcus_y + 63) // 64)
-            tiles_small = n * g.mcus_y * ((g.mcus_x + 15) // 16)
+            per_default, per_small = (64, 16) if wl.endswith("444") else (32, 8)
+            tiles_default = n * ((g.mcus_x * g.mcus_y + per_default - 1) // per_default)
+            tiles_small = n * g.mcus_y * ((g.mcus_x + per_small - 1) // per_small)
             row = {"workgroups_default": tiles_default, "workgroups_small": tiles_small, "algorithmic_bytes": res.alg_bytes}
-            for knob, name in (("0", "jb_tile_kernel<1,1>"), ("1", "jb_small_kernel_444")):
+            for knob, name in (("0", "jb_tile_kernel"), ("1", "jb_small_kernel")):
                 med = float(np.median(us[knob]))
                 row[name] = {"us_median": round(med, 2), "us_min": round(float(np.min(us[knob])), 2), "us_mean": round(float(np.mean(us[knob])), 2),
                              "GB_s": round(res.alg_bytes / med / 1e3, 1)}

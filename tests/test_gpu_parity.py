@@ -615,9 +615,10 @@ def test_reference_with_the_integration_patch(tmp_path, name):
 
 
 @pytest.mark.parametrize("byte_store", [False, True])
-def test_small_grid_444_kernel_vs_oracle(jb, oracle, monkeypatch, byte_store):
-    """jb_small_kernel_444 (JPEGBLK_SMALL_GRID=1: one wave per 16 MCUs, the variant for launches that do not fill the
-    device) against the oracle: sizes whose last tile of a row is ragged (1..15 MCUs), odd widths with tight rows and
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 2)])
+def test_small_grid_kernels_vs_oracle(jb, oracle, monkeypatch, byte_store, hs, vs):
+    """jb_small_kernel_444 / _420 (JPEGBLK_SMALL_GRID=1: one wave per 16 / 8 MCUs, the variants for launches that do not
+    fill the device) against the oracle: sizes whose last tile of a row is ragged (1..15 MCUs), odd widths with tight rows and
     padded, misaligned rows, one pixel, a batch of images with per-image tables, 16-bit table entries, and the
     1080p frame of BASELINE.json's config 2 -- with guard bytes around every image, both store paths.  The same
     inputs through the default kernel must give the same bytes (JPEGBLK_SMALL_GRID=0)."""
@@ -632,18 +633,18 @@ def test_small_grid_444_kernel_vs_oracle(jb, oracle, monkeypatch, byte_store):
     dev = torch.device("cuda:0")
     ts = torch.cuda.Stream(dev)
     cases = [(1, 1, 0, 0, 1), (8, 8, 0, 1, 1), (127, 9, 2, 1, 3), (128, 16, 0, 0, 2), (129, 17, 1, 3, 1), (333, 41, 0, 1, 2),
-             (679, 451, 0, 3, 1), (1921, 37, 5, 2, 1), (1920, 1080, 0, 0, 1), (2048, 24, 0, 0, 4)]
+             (679, 451, 0, 3, 1), (1921, 37, 5, 2, 1), (1920, 1080, 0, 0, 1), (2048, 24, 0, 0, 4), (1279, 853, 0, 1, 1), (16, 16, 0, 0, 1)]
     for (w, h, pad, off, n) in cases:
-        desc = jb.make_desc(w, h, 1, 1)
+        desc = jb.make_desc(w, h, hs, vs)
         stride = 3 * w + pad
         per = h * stride + 32
         coefs, qs, wants = [], [], []
         for i in range(n):
-            coef, q = synth.synth_blocks(w, h, 1, 1, 40 + i)
+            coef, q = synth.synth_blocks(w, h, hs, vs, 40 + i)
             if i == 1:
                 q = (q.astype(np.int64) * 97 % 4000 + 1).astype(q.dtype)   # another table per image, entries above 255
             coefs.append(coef), qs.append(jb.resolve_qtabs(desc, q))
-            wants.append(oracle.blocks_to_rgb(odesc(w, h, 1, 1), coef, q, nthreads=8))
+            wants.append(oracle.blocks_to_rgb(odesc(w, h, hs, vs), coef, q, nthreads=8))
         results = {}
         for knob in ("1", "0"):
             monkeypatch.setenv("JPEGBLK_SMALL_GRID", knob)
