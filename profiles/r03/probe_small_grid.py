@@ -43,7 +43,7 @@ def main():
                             ("640x360-444", 1, 64), ("4096x4096-444", 1, 4),
                             ("640x360-420", 1, 64), ("1920x1080-420", 1, 64), ("1920x1080-420", 4, 16), ("1920x1080-420", 8, 8),
                             ("4096x4096-420", 1, 8), ("4096x4096-420", 2, 4), ("4096x4096-420", 4, 2), ("4096x4096-420", 8, 1),
-                            ("1920x1080-420", 32, 2)]:
+                            ("1920x1080-420", 32, 2), ("679x451-420", 512, 2), ("679x451-444", 512, 2), ("427x640-420", 512, 2)]:
             res = bench.Resident(jb, torch, dev, wl, n, sets, seed=1)
             us = {"0": [], "1": []}
             for rnd in range(4):
