@@ -50,6 +50,8 @@
  *   JPEGBLK_CHUNK_BYTES    64 | 128: scan bytes per lane of the device entropy decoder (default 128)
  *   JPEGBLK_BYTE_STORE     1 = every pixel through byte stores (the second store implementation)
  *   JPEGBLK_ROW_TILING     1 = the row-bound tiling for every image
+ *   JPEGBLK_PASS1          1 = a batch run always reads every file's headers first (default: only while the decoder's
+ *                          buffers do not exist yet; otherwise a file is parsed when its group is formed)
  *   JPEGBLK_GROUP_MB       MB of coefficients per group of small images on the host path (16; 0 = one image per submission)
  *   JPEGBLK_DEV_GROUP_MB   MB of coefficients per group whose entropy stage runs on the device (96)
  *   JPEGBLK_NUMA           0 = leave the host threads' CPU affinity alone, 1 = always bind them to the GPU's node

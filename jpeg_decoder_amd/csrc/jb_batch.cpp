@@ -11,6 +11,7 @@
 // thread: the host thread that finished an image is running by definition, so a submission never
 // waits for the scheduler; a full ring blocks the submitter (back-pressure), and every thread
 // waits for its own images outside the mutex.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -126,6 +127,7 @@ struct Parsed {
   uint16_t qtabs[256];
   int status = JB_OK;
   std::string error;
+  bool have = true;  // headers parsed (false: a run without pass 1 parses a file when its group is formed)
 };
 
 constexpr int kMaxSlots = 4;
@@ -268,6 +270,11 @@ struct Run {
   Shared *dev;
   Totals *tot;
   const JbKnobs *knobs;  // the decoder's (jb_knobs.h)
+  // no pass 1: every file is read and parsed when its group is formed; an image the decoder's buffers do not hold
+  // is left for a second, classic round (deferred[t]: positions in thread t's list)
+  bool lazy = false;
+  std::vector<std::vector<int>> *deferred = nullptr;
+  size_t slot_coef = 0, slot_rgb = 0;  // what a ring slot holds (one image may be larger than a group's bound, not than this)
 };
 
 // pass 1 (per host thread): parse the headers of its files, so that the buffers can be sized once for
@@ -349,6 +356,29 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
       p.bytes.clear();
     }
     t_read += now_s() - a;
+  };
+  // (a run without pass 1) headers of file k of this thread's list, from the whole file; -> false: the image does
+  // not fit the buffers this decoder has (it waits for the second round)
+  auto ready = [&](int k) {
+    Parsed &p = parsed[(size_t)k];
+    if (!p.have) {
+      const int i = (*r.lists)[(size_t)t][(size_t)k];
+      const double a = now_s();
+      const bool ok = read_file(r.paths[i], p.bytes);
+      t_read += now_s() - a;
+      p.have = true;
+      p.loaded = ok;
+      if (ok) {
+        parse_one(p);
+      } else {
+        p.status = JB_ERR_FORMAT;
+        p.error = "cannot read file";
+        p.bytes.clear();
+      }
+    }
+    if (!r.lazy || p.status != JB_OK) return true;
+    const size_t c = (size_t)p.geo.coef_bytes, x = (size_t)p.geo.rgb_bytes;
+    return c <= lane->cap_coef && x <= lane->cap_rgb && c <= r.slot_coef && x <= r.slot_rgb;
   };
   struct Group {
     int ticket = -1, first = -1, n = 0;  // images first .. first+n-1 of this thread's list
@@ -443,6 +473,13 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
   int dev_groups = 0;  // device-entropy groups this thread has submitted
   while (k < n_mine) {
     Parsed &head = parsed[(size_t)k];
+    if (!ready(k)) {  // (a run without pass 1) larger than anything this decoder is sized for: the second round's
+      (*r.deferred)[(size_t)t].push_back(k);
+      head.bytes.clear();
+      head.bytes.shrink_to_fit();
+      k++;
+      continue;
+    }
     load(head, index_of(k));
     r.rgb[index_of(k)] = nullptr;
     r.widths[index_of(k)] = r.heights[index_of(k)] = 0;
@@ -481,6 +518,7 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     std::vector<std::unique_ptr<JbHuffJob>> jobs;
     while (n < (on_device ? room_dev : room) && k + n < n_mine) {
       Parsed &p = parsed[(size_t)(k + n)];
+      if (n > 0 && !ready(k + n)) break;  // (the next group's head: it is set aside there)
       if (n > 0 && (p.status != JB_OK || !same_geometry(head, p))) break;
       load(p, index_of(k + n));
       if (p.status != JB_OK) break;  // (n > 0: the head was loaded above; the next group reports it)
@@ -739,42 +777,14 @@ int create_single(int device_id, int n_threads, size_t max_coef_bytes, size_t ma
 // one device's share of a run; `top` = this decoder owns the arena (and recycles it)
 int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8_t **rgb, int32_t *widths,
                int32_t *heights, int *statuses, double *times, bool top) {
-  int n_threads = (int)d->lanes.size();
-  if (n_threads > n_paths && n_paths > 0) n_threads = n_paths;
   Totals tot;
   Shared dev;
-  // which files each thread owns: file i -> thread i % n_threads
-  std::vector<std::vector<int>> lists((size_t)n_threads);
-  for (int i = 0; i < n_paths; i++) lists[(size_t)(i % n_threads)].push_back(i);
-  Run r{d->device, 0, 0, d->slots(), paths, n_paths, n_threads, n_threads > 0 ? (int)d->lanes.size() / n_threads : 1,
-        &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot, &d->knobs};
   if (top) d->arena->used = 0;  // the previous run's images are released
   const double t0 = now_s();
-  // pass 1: headers, in parallel
-  std::vector<std::vector<Parsed>> parsed((size_t)n_threads);
-  std::vector<size_t> mc((size_t)n_threads, 0), mr((size_t)n_threads, 0);
-  std::vector<double> tr((size_t)n_threads, 0.0);
-  {
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; t++) {
-      parsed[(size_t)t].resize(lists[(size_t)t].size());
-      th.emplace_back([&, t] { parse_pass(r, t, parsed[(size_t)t], &mc[(size_t)t], &mr[(size_t)t], &tr[(size_t)t]); });
-    }
-    for (auto &x : th) x.join();
-  }
-  size_t max_coef = 0, max_rgb = 0;
-  for (int t = 0; t < n_threads; t++) {
-    if (mc[(size_t)t] > max_coef) max_coef = mc[(size_t)t];
-    if (mr[(size_t)t] > max_rgb) max_rgb = mr[(size_t)t];
-    tot.t_read += tr[(size_t)t];
-  }
-  std::string setup_text;
   // every pinned buffer and ring slot holds one large image or a group of small ones: the group
   // figure bounds the coefficient and the pixel side alike (rgb_bytes <= coef_bytes in every layout)
   size_t group_bytes = kGroupBytes;
   if (d->knobs.group_mb >= 0) group_bytes = (size_t)d->knobs.group_mb << 20;  // (JPEGBLK_GROUP_MB; 0 = one image per submission)
-  if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
-  if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
   // Groups whose entropy stage runs on the device hold about 100 MB of coefficients (JPEGBLK_DEV_GROUP_MB;
   // 8 1080p images, one 8192x8192 image, at most 64 images).  (With the first versions of the device decoder,
   // whose launches took milliseconds whatever their size, large groups paid -- 2,626 images/s in groups of
@@ -782,44 +792,121 @@ int run_single(jb_batch_decoder *d, const char *const *paths, int n_paths, uint8
   // kernels many small groups in flight are as fast or faster with host output (medians of six runs:
   // 0.171 s against 0.18 s for 1,024 1080p files; 8192x8192 +5 %) and much faster with device-resident
   // output, and the ring slots are a fifth of the size: profiles/r02b/ab_group_size_final.txt.)
-  size_t ring_bytes = 0;
-  {
-    if (d->knobs.gpu_huffman != 0) {
-      const long mb = d->knobs.dev_group_mb >= 0 ? d->knobs.dev_group_mb : 96;
-      ring_bytes = mb > 0 ? (size_t)mb << 20 : 0;
-      size_t share = (size_t)((n_paths + n_threads - 1) / (n_threads > 0 ? n_threads : 1));
-      if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;
-      if (ring_bytes > share * max_coef) ring_bytes = share * max_coef;
+  size_t dev_group_bytes = 0;
+  if (d->knobs.gpu_huffman != 0) {
+    const long mb = d->knobs.dev_group_mb >= 0 ? d->knobs.dev_group_mb : 96;
+    dev_group_bytes = mb > 0 ? (size_t)mb << 20 : 0;
+  }
+  // One round over `files` (indices into paths).  Classic: pass 1 reads every file's headers so that the buffers
+  // can be sized once for the round, then pass 2 decodes.  Lazy (a decoder whose buffers exist already: created
+  // with sizes, or after an earlier run): no pass 1 -- a file is read once and parsed when its group is formed, so
+  // the device has its first work after two files' worth of host time instead of after every header of the batch
+  // (1,024 files: 5 ms -> 1 ms to the first submission) -- and an image larger than the buffers is handed back in
+  // `left_over` for a classic round.
+  auto round = [&](const std::vector<int> &files, bool lazy, std::vector<int> *left_over) {
+    int nt = (int)d->lanes.size();
+    if (nt > (int)files.size()) nt = (int)files.size();
+    if (nt < 1) return;
+    std::vector<std::vector<int>> lists((size_t)nt);
+    for (size_t j = 0; j < files.size(); j++) lists[j % (size_t)nt].push_back(files[j]);  // file j -> thread j % nt
+    std::vector<std::vector<int>> deferred((size_t)nt);
+    Run r{d->device, 0, 0, d->slots(), paths, n_paths, nt, (int)d->lanes.size() / nt,
+          &lists, rgb, widths, heights, statuses, d->arena, &dev, &tot, &d->knobs};
+    r.lazy = lazy;
+    r.deferred = &deferred;
+    const double tr0 = now_s();
+    std::vector<std::vector<Parsed>> parsed((size_t)nt);
+    for (int t = 0; t < nt; t++) parsed[(size_t)t].resize(lists[(size_t)t].size());
+    int setup_rc = JB_OK;
+    std::string setup_text;
+    size_t ring_bytes = dev_group_bytes;
+    double t_parsed = tr0;
+    if (!lazy) {
+      // pass 1: headers, in parallel
+      std::vector<size_t> mc((size_t)nt, 0), mr((size_t)nt, 0);
+      std::vector<double> tr((size_t)nt, 0.0);
+      {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+          th.emplace_back([&, t] { parse_pass(r, t, parsed[(size_t)t], &mc[(size_t)t], &mr[(size_t)t], &tr[(size_t)t]); });
+        for (auto &x : th) x.join();
+      }
+      size_t max_coef = 0, max_rgb = 0;
+      for (int t = 0; t < nt; t++) {
+        if (mc[(size_t)t] > max_coef) max_coef = mc[(size_t)t];
+        if (mr[(size_t)t] > max_rgb) max_rgb = mr[(size_t)t];
+        tot.t_read += tr[(size_t)t];
+      }
+      if (max_coef && max_coef < group_bytes) max_coef = group_bytes;
+      if (max_rgb && max_rgb < group_bytes) max_rgb = group_bytes;
+      if (ring_bytes) {
+        size_t share = (files.size() + (size_t)nt - 1) / (size_t)nt;
+        if (share > (size_t)kMaxGroup) share = (size_t)kMaxGroup;
+        if (ring_bytes > share * max_coef) ring_bytes = share * max_coef;
+      }
+      t_parsed = now_s();
+      setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, nt, ring_bytes, ring_bytes) : JB_OK;
+      // a device group is bounded by this round's group size (the ring slots may be larger: an earlier run's)
+      const size_t group_cap = ring_bytes > max_coef ? ring_bytes : max_coef;
+      r.dev_cap_coef = (ring_bytes && group_cap < d->ctx_coef) ? group_cap : d->ctx_coef;
+      r.dev_cap_rgb = (ring_bytes && group_cap < d->ctx_rgb) ? group_cap : d->ctx_rgb;
+    } else {
+      for (auto &list : parsed)
+        for (Parsed &p : list) p.have = false;
+      // the buffers as they are (this call only re-makes what a change of output mode or ring depth asks for)
+      size_t lc = 0, lr = 0;
+      for (const Lane &l : d->lanes) {
+        if (l.cap_coef > lc) lc = l.cap_coef;
+        if (l.cap_rgb > lr) lr = l.cap_rgb;
+      }
+      setup_rc = d->ensure_all(lc, lr, nt, d->ctx_coef, d->ctx_rgb);
+      r.dev_cap_coef = (ring_bytes && ring_bytes < d->ctx_coef) ? ring_bytes : d->ctx_coef;
+      r.dev_cap_rgb = (ring_bytes && ring_bytes < d->ctx_rgb) ? ring_bytes : d->ctx_rgb;
     }
+    r.slot_coef = d->ctx_coef;
+    r.slot_rgb = d->ctx_rgb;
+    const double t_setup = now_s();
+    if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
+    // pass 2: entropy decoding on the host threads, all submitting to the shared context
+    dev.ctx = d->ctx;
+    {
+      // of two batches in flight on one device (submit / collect, or two decoders) the older one's downloads go first
+      static std::atomic<uint64_t> run_seq{0};
+      jb_ctx_set_download_age_(d->ctx, ++run_seq);
+    }
+    tot.first_submit = tot.first_back = tot.first_thread_done = 1e30;
+    tot.last_submit = 0;
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] { decode_pass(r, &d->lanes[(size_t)t], t, parsed[(size_t)t], setup_rc, setup_text); });
+      for (auto &x : th) x.join();
+    }
+    if (left_over)
+      for (int t = 0; t < nt; t++)
+        for (int k : deferred[(size_t)t]) left_over->push_back(lists[(size_t)t][(size_t)k]);
+    if (d->knobs.timing == 3)
+      fprintf(stderr, "run_single %zu files%s: headers %.2f ms, setup %.2f, first submit at %.2f, first group back at %.2f, last submit at %.2f, "
+              "first thread done at %.2f, all done at %.2f\n", files.size(), lazy ? " (no pass 1)" : "", (t_parsed - tr0) * 1e3, (t_setup - t_parsed) * 1e3,
+              (tot.first_submit - tr0) * 1e3, (tot.first_back - tr0) * 1e3, (tot.last_submit - tr0) * 1e3, (tot.first_thread_done - tr0) * 1e3,
+              (now_s() - tr0) * 1e3);
+  };
+  std::vector<int> all((size_t)(n_paths > 0 ? n_paths : 0));
+  for (int i = 0; i < n_paths; i++) all[(size_t)i] = i;
+  // without pass 1 when every buffer exists: the ring, and the staging of every lane this run uses
+  bool lazy = !d->knobs.pass1 && d->ctx && d->ctx_coef > 0 && d->ctx_rgb > 0;
+  for (size_t t = 0; lazy && t < d->lanes.size() && t < all.size(); t++) lazy = d->lanes[t].cap_coef > 0 && d->lanes[t].cap_rgb > 0;
+  if (lazy) {
+    std::vector<int> left;
+    round(all, true, &left);
+    if (!left.empty()) {
+      std::sort(left.begin(), left.end());
+      round(left, false, nullptr);
+    }
+  } else {
+    round(all, false, nullptr);
   }
-  const double t_parsed = now_s();
-  int setup_rc = max_coef ? d->ensure_all(max_coef, max_rgb, n_threads, ring_bytes, ring_bytes) : JB_OK;
-  const double t_setup = now_s();
-  if (setup_rc != JB_OK) setup_text = jb_last_error(nullptr);
-  // a device group is bounded by this run's group size (the ring slots may be larger: an earlier run's)
-  const size_t group_cap = ring_bytes > max_coef ? ring_bytes : max_coef;
-  r.dev_cap_coef = (ring_bytes && group_cap < d->ctx_coef) ? group_cap : d->ctx_coef;
-  r.dev_cap_rgb = (ring_bytes && group_cap < d->ctx_rgb) ? group_cap : d->ctx_rgb;
-  // pass 2: entropy decoding on the host threads, all submitting to the shared context
-  dev.ctx = d->ctx;
-  {
-    // of two batches in flight on one device (submit / collect, or two decoders) the older one's downloads go first
-    static std::atomic<uint64_t> run_seq{0};
-    jb_ctx_set_download_age_(d->ctx, ++run_seq);
-  }
-  {
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; t++)
-      th.emplace_back([&, t] { decode_pass(r, &d->lanes[(size_t)t], t, parsed[(size_t)t], setup_rc, setup_text); });
-    for (auto &x : th) x.join();
-  }
-  const double t_joined = now_s();
-  jb_ctx_synchronize(d->ctx);
-  if (d->knobs.timing == 3)
-    fprintf(stderr, "run_single %d files: headers %.2f ms, setup %.2f, first submit at %.2f, first group back at %.2f, last submit at %.2f, "
-            "first thread done at %.2f, all done at %.2f, synchronised at %.2f\n", n_paths, (t_parsed - t0) * 1e3, (t_setup - t_parsed) * 1e3,
-            (tot.first_submit - t0) * 1e3, (tot.first_back - t0) * 1e3, (tot.last_submit - t0) * 1e3, (tot.first_thread_done - t0) * 1e3,
-            (t_joined - t0) * 1e3, (now_s() - t0) * 1e3);
+  if (d->ctx) jb_ctx_synchronize(d->ctx);
   if (times) {
     times[0] = now_s() - t0;
     times[1] = tot.t_entropy;
