@@ -416,3 +416,40 @@ def test_batch_decoder_submit_collect_stream(jb, oracle, tmp_path, monkeypatch, 
             pixels(dec.run(batches[4][0]), batches[4][1])
         # a batch still in flight when the decoder is destroyed finishes first
         dec.submit(batches[0][0])
+
+
+@pytest.mark.parametrize("entropy", ["host", "device"])
+@pytest.mark.parametrize("arena", [False, True])
+def test_batch_decoder_later_runs_skip_pass_1_and_set_larger_images_aside(jb, oracle, tmp_path, monkeypatch, arena, entropy):
+    """Once a decoder's buffers exist a run has no pass 1: files are parsed as their groups are formed, and an image
+    larger than the buffers is decoded in a second, classic round that re-sizes them.  Run 1: small images (sizes the
+    decoder); run 2: the same plus larger images of another sampling in between, one of them unreadable; run 3: all
+    again (everything fits now); each against the oracle, and JPEGBLK_PASS1=1 gives the same."""
+    if entropy == "device":
+        monkeypatch.delenv("JPEGBLK_GPU_HUFFMAN", raising=False)
+    else:
+        monkeypatch.setenv("JPEGBLK_GPU_HUFFMAN", "0")
+    small_p, small_w = _write_files(str(tmp_path), "s", 333, 211, 1, 1, 9, 3, 0, oracle)
+    big_p, big_w = _write_files(str(tmp_path), "b", 1024, 768, 2, 2, 4, 2, 0, oracle)
+    huge_p, huge_w = _write_files(str(tmp_path), "h", 2048, 1536, 1, 1, 1, 1, 16, oracle)
+    missing = str(tmp_path / "does_not_exist.jpg")
+    mixed_p = small_p[:2] + big_p[:1] + small_p[2:5] + [missing] + huge_p + big_p[1:] + small_p[5:]
+    mixed_w = small_w[:2] + big_w[:1] + small_w[2:5] + [None] + huge_w + big_w[1:] + small_w[5:]
+    total = sum((w.size + 255) // 256 * 256 for w in mixed_w + small_w if w is not None) + 4096   # the largest run's worth
+
+    def check(result, want):
+        imgs, st, tm = result
+        for i, w in enumerate(want):
+            if w is None:
+                assert st[i] == -8 and imgs[i] is None, (i, st[i])
+            else:
+                assert st[i] == 0 and np.array_equal(imgs[i], w), (i, st[i])
+
+    for pass1 in ("0", "1"):
+        monkeypatch.setenv("JPEGBLK_PASS1", pass1)
+        with jb.BatchDecoder(4, 0, arena_bytes=total if arena else 0) as dec:
+            check(dec.run(small_p), small_w)
+            check(dec.run(mixed_p), mixed_w)
+            check(dec.run(mixed_p + small_p), mixed_w + small_w)
+            if entropy == "device":
+                assert dec.device_entropy_images > 0

@@ -73,7 +73,8 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
-    n_batches = n_images = n_bad = n_dev = n_streamed = 0
+    n_batches = n_images = n_bad = n_dev = n_streamed = n_veteran = 0
+    veteran = None
     pixels = 0
     # the reference context keeps the entropy stage on the host (a context reads its knobs when it is created)
     os.environ["JPEGBLK_GPU_HUFFMAN"] = "0"
@@ -110,23 +111,34 @@ def main():
             arena = 0
             if rng.random() < 0.5:
                 arena = sum(distinct[i][2] for i in order) + 4096
-            with jb.BatchDecoder(threads, 0, arena_bytes=arena) as dec:
-                mode = rng.random()
-                if mode < 0.6:
-                    imgs, st, tm = dec.run(paths)
-                else:
-                    # the same batch through submit / collect: as two halves in flight at once (each side's arena holds
-                    # the whole batch's worth), sometimes with a plain run on the same decoder in front
-                    if mode < 0.7:
-                        dec.run(paths[:3], keep_pixels=False)
-                    cut = int(rng.integers(0, n + 1))
-                    ta = dec.submit(paths[:cut])
-                    tb = dec.submit(paths[cut:])
-                    ia, sa, _ = dec.collect(ta)
-                    ib, sb, _ = dec.collect(tb)
-                    imgs, st = ia + ib, sa + sb
-                    n_streamed += 1
-                n_dev += dec.device_entropy_images
+            # one batch in three goes to a decoder that lives on across batches (malloc'ed outputs, 5 threads): its runs
+            # have no pass 1, and whatever is larger than the buffers it has grown so far takes the second round
+            if arena == 0 and rng.random() < 0.33:
+                if veteran is None:
+                    veteran = jb.BatchDecoder(5, 0)
+                imgs, st, tm = veteran.run(paths)
+                n_veteran += 1
+                dec = None
+            else:
+                dec = jb.BatchDecoder(threads, 0, arena_bytes=arena)
+            if dec is not None:
+                with dec:
+                    mode = rng.random()
+                    if mode < 0.6:
+                        imgs, st, tm = dec.run(paths)
+                    else:
+                        # the same batch through submit / collect: as two halves in flight at once (each side's arena holds
+                        # the whole batch's worth), sometimes with a plain run on the same decoder in front
+                        if mode < 0.7:
+                            dec.run(paths[:3], keep_pixels=False)
+                        cut = int(rng.integers(0, n + 1))
+                        ta = dec.submit(paths[:cut])
+                        tb = dec.submit(paths[cut:])
+                        ia, sa, _ = dec.collect(ta)
+                        ib, sb, _ = dec.collect(tb)
+                        imgs, st = ia + ib, sa + sb
+                        n_streamed += 1
+                    n_dev += dec.device_entropy_images
             for j, i in enumerate(order):
                 want = distinct[i][1]
                 if isinstance(want, int):
@@ -137,7 +149,10 @@ def main():
                     pixels += want.size // 3
             n_batches += 1
             n_images += n
-    print(f"batch soak ok: {n_batches} batches ({n_streamed} of them as two halves through submit / collect), {n_images} images ({n_bad} rejected as by the single-image host decode, "
+    if veteran is not None:
+        n_dev += veteran.device_entropy_images
+        veteran.close()
+    print(f"batch soak ok: {n_batches} batches ({n_streamed} of them as two halves through submit / collect, {n_veteran} on one long-lived decoder), {n_images} images ({n_bad} rejected as by the single-image host decode, "
           f"{n_dev} entropy-decoded on the device), {pixels / 1e9:.2f} Gpixels compared, {time.time() - t0:.0f} s, seed {args.seed}")
 
 
