@@ -211,7 +211,9 @@ typedef struct jb_device_batch {
 int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *batch, void *stream);
 /* Host helper: expand (qtabs uint16[4][64], qtab_id[3]) into the int32[3][64] the kernel reads. */
 int jb_resolve_qtabs(const jb_image_desc *desc, const uint16_t *qtabs, int32_t *out192);
-/* Name of the kernel jb_blocks_to_rgb_device launches for this descriptor (for profilers). */
+/* Name of the kernel jb_blocks_to_rgb_device launches for this descriptor (for profilers): the 192 / 256-lane
+ * kernel of the layout.  4:4:4 and 4:2:0 launches of up to 8 of its workgroups per CU (one to four 1080p images,
+ * one 4096x4096 4:2:0) run as jb_small_kernel_444 / jb_small_kernel_420 instead (JPEGBLK_SMALL_GRID). */
 const char *jb_kernel_name(const jb_image_desc *desc);
 
 /* ---- host front end ("next" rows of the scope table; reference jpeg.cpp:67-446, 826-907,
