@@ -325,14 +325,15 @@ class Resident:
         self.alg_bytes = nimg * (g.n_coded_blocks * 128 + self.w * self.h * 3)  # 128 B/block in + 3 B/pixel out
         self.pixels = nimg * self.w * self.h
         self.kernel = jb.lib().jb_kernel_name(self.desc).decode()
-        # 4:4:4 and 4:2:0 launches of up to 8 workgroups per CU take the one-wave kernels (csrc/jb_api.cpp
+        # launches of up to 8 workgroups per CU take the one-wave kernels (csrc/jb_api.cpp
         # kSmallGridBelowPerCu; JPEGBLK_SMALL_GRID forces either)
-        per_tile = {(1, 1): 64, (2, 2): 32}.get((self.hs, self.vs))
+        per_tile = {(1, 1): 64, (2, 2): 32, (2, 1): 64, (1, 2): 64}.get((self.hs, self.vs))
         knob = os.environ.get("JPEGBLK_SMALL_GRID", "")[:1]
         if per_tile:
             tiles = nimg * ((g.mcus_x * g.mcus_y + per_tile - 1) // per_tile)
             if knob == "1" or (knob != "0" and tiles <= 8 * torch.cuda.get_device_properties(dev).multi_processor_count):
-                self.kernel = "jb_small_kernel_444" if self.hs == 1 else "jb_small_kernel_420"
+                self.kernel = {(1, 1): "jb_small_kernel_444", (2, 2): "jb_small_kernel_420", (2, 1): "jb_small_kernel_16<2, 1>",
+                               (1, 2): "jb_small_kernel_16<1, 2>"}[(self.hs, self.vs)]
 
 
 def main():

@@ -58,7 +58,7 @@
  *   JPEGBLK_OVERSUBSCRIBE  1 = allow more host threads than CPUs the process may use
  *   JPEGBLK_STAGED_STORE   1 = (measurement builds of the kernels only, tools/build_variant.sh; the product ignores it) the
  *                          staged, line-aligned store stage for every image that takes the linear tiling
- *   JPEGBLK_SMALL_GRID     4:4:4 and 4:2:0 launches: 1 = always the one-wave kernels, 0 = never (default: launches of
+ *   JPEGBLK_SMALL_GRID     1 = always the one-wave kernels (every layout has one), 0 = never (default: launches of
  *                          up to 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images, one 4096x4096 4:2:0)
  *   JPEGBLK_TIMING         1 | 2 | 3 = where one decode(bytes) / one device-entropy submission / one batch run spends its time (stderr)
  *   JPEGBLK_HW_QUEUES      read when the library is LOADED: hardware queues to ask the HIP runtime for
@@ -212,8 +212,8 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *batch, void *str
 /* Host helper: expand (qtabs uint16[4][64], qtab_id[3]) into the int32[3][64] the kernel reads. */
 int jb_resolve_qtabs(const jb_image_desc *desc, const uint16_t *qtabs, int32_t *out192);
 /* Name of the kernel jb_blocks_to_rgb_device launches for this descriptor (for profilers): the 192 / 256-lane
- * kernel of the layout.  4:4:4 and 4:2:0 launches of up to 8 of its workgroups per CU (one to four 1080p images,
- * one 4096x4096 4:2:0) run as jb_small_kernel_444 / jb_small_kernel_420 instead (JPEGBLK_SMALL_GRID). */
+ * kernel of the layout.  Launches of up to 8 of its workgroups per CU (one to four 1080p images, one 4096x4096
+ * 4:2:0) run as jb_small_kernel_444 / _420 / _16<2,1> / _16<1,2> instead (JPEGBLK_SMALL_GRID). */
 const char *jb_kernel_name(const jb_image_desc *desc);
 
 /* ---- host front end ("next" rows of the scope table; reference jpeg.cpp:67-446, 826-907,

@@ -506,12 +506,13 @@ int jb_ctx_synchronize(jb_ctx *ctx) {
   return JB_OK;
 }
 
-// 4:4:4 and 4:2:0 launches of up to this many 192-lane workgroups per CU take the small-grid kernels when
+// Launches of up to this many 192 / 256-lane workgroups per CU take the small-grid kernels when
 // JPEGBLK_SMALL_GRID is unset.  Measured on one box, cold, events around every launch, the kernels interleaved
 // (profiles/r03/probe_small_grid.json).  4:4:4: one 1080p image (507 workgroups) 12.1 -> 10.2 us, two (1,014)
 // 14.6 -> 13.6, four (2,028) 21.5 -> 20.5, one 1280x720 9.4 -> 8.4, one 640x360 9.4 -> 7.1, one 4096x4096 (4,096)
 // 33.6 = 33.9.  4:2:0: one 640x360 11.3 -> 7.8 us, one 1080p (255 workgroups) 12.2 -> 9.4, four (1,020) 17.3 -> 15.6,
 // eight (2,040) 28.0 -> 25.7, one 4096x4096 (2,048: BASELINE config 3) 27.5 -> 25.6, two (4,096) 44.6 -> 43.1.
+// 4:2:2 / 4:4:0 (all 64 lanes busy): one 1080p 11.2 -> 10.6 / 11.4 -> 9.6 us, one 4096x4096 25.0 -> 23.4 / 25.7 -> 26.3.
 constexpr int kSmallGridBelowPerCu = 8;
 
 int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream) {
@@ -555,8 +556,8 @@ int jb_blocks_to_rgb_device(jb_ctx *ctx, const jb_device_batch *b, void *stream)
   const int64_t n_tiles = (int64_t)b->n_images * tiles_per_image;
   if (n_tiles > 0x7fffffffLL) return fail(ctx, JB_ERR_CAPACITY, "batch too large for one launch (%lld tiles)", (long long)n_tiles);
   p.n_tiles = (int32_t)n_tiles;
-  // Small 4:4:4 and 4:2:0 launches (a single 1080p image is 507 / 255 workgroups on 256 CUs): four times as many
-  // one-wave workgroups (jb_kernels.hip jb_small_kernel_444 / _420), row-bound.  JPEGBLK_SMALL_GRID = 1 / 0 forces / forbids it; so does
+  // Small launches (a single 1080p image is 507 / 255 workgroups on 256 CUs): four times as many one-wave
+  // workgroups (jb_kernels.hip jb_small_kernel_*), row-bound.  JPEGBLK_SMALL_GRID = 1 / 0 forces / forbids it; so does
   // JPEGBLK_ROW_TILING=1 (that knob asks for the 192-lane kernel's row-bound instantiation).
   if (jbk_small_mcus(b->desc.hs, b->desc.vs) > 0 && !force_row && b->rgb_row_stride < (1LL << 26) &&  // (the lane's row offset is 32-bit)
       (ctx->knobs.small_grid == 1 || (ctx->knobs.small_grid < 0 && n_tiles <= (int64_t)kSmallGridBelowPerCu * ctx->n_cus))) {

@@ -937,6 +937,149 @@ __global__ __launch_bounds__(64) void jb_small_kernel_420(const JbLaunch p) {
   }
 }
 
+// 4:2:2 (HS = 2, VS = 1) and 4:4:0 (HS = 1, VS = 2): four blocks per MCU, so 16 MCUs fill a wave exactly -- lanes
+// 0-31 the luma blocks (MCU l >> 1, block l & 1: left / right, or top / bottom), 32-47 Cb, 48-63 Cr.  4:2:2: strips of
+// 4 rows x 256 luma / 128 chroma samples, a pixel row per wave-iteration; 4:4:0: 8 luma rows (rows 4p..4p+3 of both
+// block rows) x 128 samples and the 4 chroma rows they need (selected per value, as in the 4:2:0 variant), two pixel
+// rows per wave-iteration.
+template <int HS, int VS>
+__global__ __launch_bounds__(64) void jb_small_kernel_16(const JbLaunch p) {
+  static_assert((HS == 2 && VS == 1) || (HS == 1 && VS == 2), "the four-blocks-per-MCU layouts");
+  constexpr int kMcus = 16;
+  constexpr int YW = kMcus * 8 * HS;            // luma strip width in samples: 256 / 128
+  constexpr int YROWS = 4 * VS;                 // luma strip rows per phase: 4 / 8
+  constexpr int kYStrip = YROWS * YW * 4;       // 4 KiB either way
+  constexpr int kCPitch = kMcus * 8 * 4;        // 512 B: 128 chroma samples per row
+  constexpr int kCStrip = 4 * kCPitch + 64;     // 2 KiB, skewed
+  constexpr int kQPitch = 64 + 4;
+  __shared__ __attribute__((aligned(16))) char lds[kYStrip + 2 * kCStrip + 3 * kQPitch * 4];
+  int32_t *const qlds = (int32_t *)(lds + kYStrip + 2 * kCStrip);
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int img = tile / p.tiles_per_image;
+  const int rem = tile - img * p.tiles_per_image;
+  const int my = rem / p.tiles_per_row;
+  const int mx0 = (rem - my * p.tiles_per_row) * kMcus;
+  const int nvalid = min(kMcus, p.mcus_x - mx0);
+  const int comp = lane < 32 ? 0 : (lane < 48 ? 1 : 2);
+  const int m = lane < 32 ? lane >> 1 : (lane & 15);
+  const int slot = lane < 32 ? (lane & 1) : 2 + comp - 1;  // block of the MCU in decode order
+  const uint8_t *tile_coef = (const uint8_t *)p.coef + (int64_t)img * p.coef_image_stride + ((int64_t)my * p.mcus_x + mx0) * 512;
+  const int32_t *qsrc = (const int32_t *)((const uint8_t *)p.qtabs + (int64_t)img * p.qtab_image_stride);
+#pragma unroll
+  for (int i = 0; i < 3; i++) qlds[i * kQPitch + lane] = qsrc[i * 64 + lane];
+  float v[64];
+  {
+    uint32_t raw[32];
+    const u32x4_t *src = (const u32x4_t *)(tile_coef + (uint32_t)(min(m, nvalid - 1) * 4 + slot) * 128u);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32x4_t t = src[j];
+      raw[j * 4 + 0] = t.x, raw[j * 4 + 1] = t.y, raw[j * 4 + 2] = t.z, raw[j * 4 + 3] = t.w;
+    }
+    __syncthreads();  // the tables are in LDS
+    const int32_t *q = qlds + comp * kQPitch;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        const int4 q4 = *(const int4 *)(q + k * 8 + i);
+        const int qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t w = raw[k * 4 + ((i + e) >> 1)];
+          const int c = ((i + e) & 1) ? ((int)w >> 16) : (int)(short)(w & 0xffffu);
+          v[k * 8 + i + e] = (float)__mul24(c, qq[e]);  // jpeg.cpp:563-569
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++)  // column pass, jpeg.cpp:596-663
+    aan_1d(v[0 * 8 + i], v[1 * 8 + i], v[2 * 8 + i], v[3 * 8 + i], v[4 * 8 + i], v[5 * 8 + i], v[6 * 8 + i], v[7 * 8 + i]);
+#pragma unroll
+  for (int k = 0; k < 8; k++)  // row pass, jpeg.cpp:664-731
+    aan_1d(v[k * 8 + 0], v[k * 8 + 1], v[k * 8 + 2], v[k * 8 + 3], v[k * 8 + 4], v[k * 8 + 5], v[k * 8 + 6], v[k * 8 + 7]);
+
+  const bool luma = comp == 0;
+  const int bsel = lane & 1;                                     // luma: right (4:2:2) or bottom (4:4:0) block of the MCU
+  const int col = luma ? (HS == 2 ? m * 2 + bsel : m) : m;       // 8-sample column of the block in its strip
+  const int row0 = luma && VS == 2 ? bsel * 4 : 0;               // first strip row of the block
+  const int sw = (col >> 2) & 1;
+  const int pitch = luma ? YW * 4 : kCPitch;
+  char *const dst = lds + (luma ? row0 * (YW * 4) : kYStrip + (comp - 1) * kCStrip) + col * 32;
+  constexpr int TPR = YW / 4;                                    // 4-pixel tasks per row: 64 / 32
+  const int x4 = lane & (TPR - 1);
+  const int rd_y = (x4 ^ ((x4 >> 3) & 1)) * 16;
+  const int rd_c = HS == 2 ? ((x4 >> 1) ^ ((x4 >> 4) & 1)) * 16 + (x4 & 1) * 8 : rd_y;
+  uint8_t *const img_rgb = p.rgb + (int64_t)img * p.rgb_image_stride;
+  const int x = mx0 * 8 * HS + x4 * 4;
+  const int npx = min(4, min(nvalid * 8 * HS, p.width - mx0 * 8 * HS) - x4 * 4);
+#pragma unroll
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int kl = phase * 4 + kk;                                            // rows 4p .. 4p+3 of the block
+      const int kc = VS == 2 ? phase * 2 + (kk & 1) + (kk >> 1) * 4 : kl;       // 4:4:0 chroma: rows 2p, 2p+1, 4+2p, 5+2p
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (VS == 2 && !luma) ? v[kc * 8 + e] : v[kl * 8 + e];
+      *(float4 *)(dst + kk * pitch + sw * 16) = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4 *)(dst + kk * pitch + (sw ^ 1) * 16) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+    constexpr int ROWS_PER_IT = 64 / TPR;  // 1 / 2
+#pragma unroll
+    for (int it = 0; it < YROWS / ROWS_PER_IT; it++) {
+      const int r = it * ROWS_PER_IT + (ROWS_PER_IT == 2 ? lane >> 5 : 0);   // luma strip row
+      const int y_in = phase * 4 + (r >> 2) * 8 + (r & 3);
+      const int y = my * 8 * VS + y_in;
+      const float4 Y = *(const float4 *)(lds + r * (YW * 4) + rd_y);
+      float cb[4], cr[4];
+      const int crow = (r / VS) * kCPitch;
+      if (HS == 2) {
+        const float2 B = *(const float2 *)(lds + kYStrip + crow + rd_c);
+        const float2 R = *(const float2 *)(lds + kYStrip + kCStrip + crow + rd_c);
+        cb[0] = cb[1] = B.x, cb[2] = cb[3] = B.y;
+        cr[0] = cr[1] = R.x, cr[2] = cr[3] = R.y;
+      } else {
+        const float4 B = *(const float4 *)(lds + kYStrip + crow + rd_c);
+        const float4 R = *(const float4 *)(lds + kYStrip + kCStrip + crow + rd_c);
+        cb[0] = B.x, cb[1] = B.y, cb[2] = B.z, cb[3] = B.w;
+        cr[0] = R.x, cr[1] = R.y, cr[2] = R.z, cr[3] = R.w;
+      }
+      const float yy[4] = {Y.x, Y.y, Y.z, Y.w};
+      float rr[4], gg[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // jpeg.cpp:521-535
+        rr[i] = (yy[i] + JB_CR_R * cr[i]) + 128.0f;
+        gg[i] = ((yy[i] - JB_CB_G * cb[i]) - JB_CR_G * cr[i]) + 128.0f;
+        bb[i] = (yy[i] + JB_CB_B * cb[i]) + 128.0f;
+      }
+      if (p.fast_store) {
+        uint32_t w0, w1, w2;
+        pack12_rtz(rr, gg, bb, w0, w1, w2);
+        if (y < p.height && npx == 4) {
+          uint8_t *const rows = img_rgb + (int64_t)(my * 8 * VS) * p.rgb_row_stride + (int64_t)mx0 * (24 * HS);
+          const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, 0x7ffffff0, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b96(u32x3_t{w0, w1, w2}, rsrc, y_in * (int)p.rgb_row_stride + x4 * 12, 0, JB_STORE_AUX);
+        }
+      }
+      uint8_t *const o = img_rgb + (int64_t)y * p.rgb_row_stride + (int64_t)x * 3;
+      if (y < p.height && npx > 0 && (!p.fast_store || npx < 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i < npx) {
+            o[i * 3 + 0] = (uint8_t)pack_u8(rr[i], 0, 0);
+            o[i * 3 + 1] = (uint8_t)pack_u8(gg[i], 0, 0);
+            o[i * 3 + 2] = (uint8_t)pack_u8(bb[i], 0, 0);
+          }
+      }
+    }
+  }
+}
+
 template <int HS, int VS>
 static hipError_t launch_t(const JbLaunch &p, hipStream_t stream) {
   using LM = LaneMap<HS, VS>;
@@ -979,15 +1122,17 @@ int jbk_linear_ok(int hs, int vs, int mcus_x) {
   return mcus_x >= 256 / (8 * hs);
 }
 
-int jbk_small_mcus(int hs, int vs) { return hs == 1 && vs == 1 ? kSmallMcus : hs == 2 && vs == 2 ? kSmallMcus420 : 0; }
+int jbk_small_mcus(int hs, int vs) { return hs == 1 && vs == 1 ? kSmallMcus : hs == 2 && vs == 2 ? kSmallMcus420 : 16; }
 
 hipError_t jbk_launch(const JbLaunch &p, int hs, int vs, hipStream_t stream) {
   if (p.n_tiles <= 0) return hipSuccess;
-  if (p.small_grid) {  // (the host only sets it for 4:4:4 and 4:2:0, with the tile counts of this tiling)
+  if (p.small_grid) {  // (the host sets it with the tile counts of this tiling)
     if (jbk_small_mcus(hs, vs) == 0) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    if (hs == 1) hipLaunchKernelGGL(jb_small_kernel_444, dim3(p.n_tiles), dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL(jb_small_kernel_420, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    if (hs == 1 && vs == 1) hipLaunchKernelGGL(jb_small_kernel_444, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    else if (hs == 2 && vs == 2) hipLaunchKernelGGL(jb_small_kernel_420, dim3(p.n_tiles), dim3(64), 0, stream, p);
+    else if (hs == 2) hipLaunchKernelGGL((jb_small_kernel_16<2, 1>), dim3(p.n_tiles), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((jb_small_kernel_16<1, 2>), dim3(p.n_tiles), dim3(64), 0, stream, p);
     return hipGetLastError();
   }
   if (hs == 1 && vs == 1) return launch_t<1, 1>(p, stream);

@@ -15,7 +15,7 @@
 //   JPEGBLK_ROW_TILING    1: the row-bound tiling for every image (default: the linear tiling where rows are ragged)
 //   JPEGBLK_STAGED_STORE  1: (measurement builds of jb_kernels.hip with -DJB_LAB only; the product ignores it) the staged,
 //                         line-aligned store stage for every image that takes the linear tiling
-//   JPEGBLK_SMALL_GRID    4:4:4 and 4:2:0 launches: 1 = always the one-wave kernels, 0 = never (default: for launches
+//   JPEGBLK_SMALL_GRID    1 = always the one-wave kernels (every layout has one), 0 = never (default: for launches
 //                         of up to 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images, one 4096x4096 4:2:0)
 //   JPEGBLK_PASS1         1: a batch run always reads every file's headers first (default: only a decoder whose
 //                         buffers do not exist yet does; otherwise files are parsed as their groups are formed)

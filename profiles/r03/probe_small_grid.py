@@ -39,18 +39,22 @@ def main():
 
     out = {}
     with torch.cuda.stream(stream):
-        for wl, n, sets in [("1920x1080-444", 1, 32), ("1920x1080-444", 2, 16), ("1920x1080-444", 4, 8), ("1280x720-444", 1, 64),
+        import os as _os
+        big = [("4096x4096-422", 8, 1), ("4096x4096-422", 16, 1), ("8192x8192-422", 4, 1), ("4096x4096-440", 8, 1), ("1920x1080-422", 128, 1), ("679x451-422", 512, 2)]
+        for wl, n, sets in (big if _os.environ.get("PROBE_BIG") else [("1920x1080-444", 1, 32), ("1920x1080-444", 2, 16), ("1920x1080-444", 4, 8), ("1280x720-444", 1, 64),
                             ("640x360-444", 1, 64), ("4096x4096-444", 1, 4),
                             ("640x360-420", 1, 64), ("1920x1080-420", 1, 64), ("1920x1080-420", 4, 16), ("1920x1080-420", 8, 8),
                             ("4096x4096-420", 1, 8), ("4096x4096-420", 2, 4), ("4096x4096-420", 4, 2), ("4096x4096-420", 8, 1),
-                            ("1920x1080-420", 32, 2), ("679x451-420", 512, 2), ("679x451-444", 512, 2), ("427x640-420", 512, 2)]:
+                            ("1920x1080-420", 32, 2), ("679x451-420", 512, 2), ("679x451-444", 512, 2), ("427x640-420", 512, 2),
+                            ("640x360-422", 1, 64), ("1920x1080-422", 1, 32), ("1920x1080-422", 4, 8), ("4096x4096-422", 1, 4), ("4096x4096-422", 4, 1),
+                            ("640x360-440", 1, 64), ("1920x1080-440", 1, 32), ("1920x1080-440", 4, 8), ("4096x4096-440", 1, 4), ("4096x4096-440", 4, 1)]):
             res = bench.Resident(jb, torch, dev, wl, n, sets, seed=1)
             us = {"0": [], "1": []}
             for rnd in range(4):
                 for knob in ("0", "1"):
                     us[knob] += timed(ctxs[knob], res, 200)
             g = res.g
-            per_default, per_small = (64, 16) if wl.endswith("444") else (32, 8)
+            per_default, per_small = (32, 8) if wl.endswith("420") else (64, 16)
             tiles_default = n * ((g.mcus_x * g.mcus_y + per_default - 1) // per_default)
             tiles_small = n * g.mcus_y * ((g.mcus_x + per_small - 1) // per_small)
             row = {"workgroups_default": tiles_default, "workgroups_small": tiles_small, "algorithmic_bytes": res.alg_bytes}

@@ -615,10 +615,10 @@ def test_reference_with_the_integration_patch(tmp_path, name):
 
 
 @pytest.mark.parametrize("byte_store", [False, True])
-@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 2)])
+@pytest.mark.parametrize("hs,vs", [(1, 1), (2, 2), (2, 1), (1, 2)])
 def test_small_grid_kernels_vs_oracle(jb, oracle, monkeypatch, byte_store, hs, vs):
-    """jb_small_kernel_444 / _420 (JPEGBLK_SMALL_GRID=1: one wave per 16 / 8 MCUs, the variants for launches that do not
-    fill the device) against the oracle: sizes whose last tile of a row is ragged (1..15 MCUs), odd widths with tight rows and
+    """jb_small_kernel_444 / _420 / _16<2,1> / _16<1,2> (JPEGBLK_SMALL_GRID=1: one wave per 16 / 8 / 16 / 16 MCUs, the
+    variants for launches that do not fill the device) against the oracle: sizes whose last tile of a row is ragged (1..15 MCUs), odd widths with tight rows and
     padded, misaligned rows, one pixel, a batch of images with per-image tables, 16-bit table entries, and the
     1080p frame of BASELINE.json's config 2 -- with guard bytes around every image, both store paths.  The same
     inputs through the default kernel must give the same bytes (JPEGBLK_SMALL_GRID=0)."""
