@@ -938,6 +938,9 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     // the download thread issues the copies once the kernels have finished (jb_ctx::dl_*; against the copies on the
     // submission's own stream: 1,024 1080p files 6,467-7,008 -> 7,742-7,815 images/s, 128 files 4,257-4,318 ->
     // 5,767-6,567, 64 8192x8192 files 227-238 -> 262: profiles/r03/ab_download_thread.txt)
+    // (the status words travel on the submission's own stream, in front of `computed`: on the engine's stream the
+    // small copy and its latency would sit between every two pixel copies of the device)
+    JB_HIP(ctx, hipMemcpyAsync(status_out ? status_out : s.h_status, s.d_status, 4 * (size_t)n_images, hipMemcpyDeviceToHost, up));
     JB_HIP(ctx, hipEventRecord(s.computed, up));
     DlItem it;
     it.ctx = ctx;
@@ -947,9 +950,9 @@ int submit_jobs_impl(jb_ctx *ctx, const JbHuffJob *const *jobs, const uint8_t *p
     it.rows = 0, it.dst_pitch = it.src_pitch = it.row_bytes = 0;
     if (rgb_stride != dev_stride)
       it.rows = (size_t)desc->height, it.dst_pitch = (size_t)rgb_stride, it.src_pitch = (size_t)dev_stride, it.row_bytes = (size_t)desc->width * 3;
-    it.status_dst = status_out ? (void *)status_out : (void *)s.h_status;
-    it.status_src = s.d_status;
-    it.status_bytes = 4 * (size_t)n_images;
+    it.status_dst = nullptr;
+    it.status_src = nullptr;
+    it.status_bytes = 0;
     rc = dl_enqueue(ctx, it);
     if (rc) return rc;
   }
@@ -1203,7 +1206,10 @@ int jb_check_device_region_(int device, const void *p, size_t bytes) {
   return JB_OK;
 }
 
-int jb_bind_thread_near_device_(int device, int numa_knob) {  // numa_knob: JbKnobs::numa of the calling decoder
+// which CPUs the threads of a decoder on `device` are bound to (n = 0: none): worked out once per (device, knob) --
+// sysfs, the cgroup quota and the affinity mask of the first caller, 16 threads of every pass of every run asked for
+// them again -- then only applied
+static int numa_cpus_for_(int device, int numa_knob, cpu_set_t *out) {
   if (numa_knob == 0) return 0;
   const bool forced = numa_knob == 1;
   const int node = jb_device_numa_node(device);
@@ -1247,8 +1253,32 @@ int jb_bind_thread_near_device_(int device, int numa_knob) {  // numa_knob: JbKn
     }
     if (quota > 0 && period > 0 && quota / period < n) return 0;
   }
-  if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
+  *out = want;
   return n;
+}
+
+int jb_bind_thread_near_device_(int device, int numa_knob) {  // numa_knob: JbKnobs::numa of the calling decoder
+  struct Entry {
+    int n;
+    cpu_set_t set;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, Entry> cache;
+  Entry e;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find({device, numa_knob});
+    if (it == cache.end()) {
+      Entry fresh;
+      CPU_ZERO(&fresh.set);
+      fresh.n = numa_cpus_for_(device, numa_knob, &fresh.set);
+      it = cache.emplace(std::make_pair(device, numa_knob), fresh).first;
+    }
+    e = it->second;
+  }
+  if (e.n <= 0) return 0;
+  if (sched_setaffinity(0, sizeof e.set, &e.set) != 0) return 0;
+  return e.n;
 }
 
 void jb_ctx_set_last_desc_(jb_ctx *ctx, const jb_image_desc *d) { ctx->last_desc = *d; }

@@ -176,8 +176,11 @@ struct Lane {
     if (!coef[s]) coef[s] = (int16_t *)jb_pinned_alloc_on(device_of_bufs, cap_coef);
     return coef[s];
   }
+  bool satisfied(size_t need_coef, size_t need_rgb, bool with_out, int n_slots) const {
+    return status[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out) && n_alloc >= n_slots;
+  }
   int ensure(int device, size_t need_coef, size_t need_rgb, bool with_out, int n_slots) {
-    if (status[0] && need_coef <= cap_coef && need_rgb <= cap_rgb && (has_out || !with_out) && n_alloc >= n_slots) return JB_OK;
+    if (satisfied(need_coef, need_rgb, with_out, n_slots)) return JB_OK;
     if (need_coef < cap_coef) need_coef = cap_coef;
     if (need_rgb < cap_rgb) need_rgb = cap_rgb;
     release();
@@ -718,6 +721,14 @@ struct jb_batch_decoder {
     int rc = ensure_ctx(ring_coef > need_coef ? ring_coef : need_coef, ring_rgb > need_rgb ? ring_rgb : need_rgb);
     if (rc != JB_OK) return rc;
     const bool with_out = !arena->base;
+    {
+      // nothing to make (every run after the first): no threads either -- sixteen of them started and joined for
+      // nothing took half a millisecond of every run
+      bool all = true;
+      const int n_slots_now = slots();
+      for (int i = 0; i < n_lanes && all; i++) all = lanes[(size_t)i].satisfied(need_coef, need_rgb, with_out, n_slots_now);
+      if (all) return JB_OK;
+    }
     std::vector<std::thread> th;
     std::vector<int> rcs((size_t)n_lanes, JB_OK);
     const int dev = device;
