@@ -814,8 +814,7 @@ int huff_stage(jb_ctx *ctx, Slot &s, const uint8_t *h, const JbHuffLayout &lay, 
   if (lay.total <= ((size_t)4 << 20)) JB_HIP(ctx, jbk_huff_fetch(s.d_blob, h, lay.total, up));
   else JB_HIP(ctx, hipMemcpyAsync(s.d_blob, h, lay.total, hipMemcpyHostToDevice, up));
   // the decoder stores non-zero coefficients only
-  JB_HIP(ctx, jbk_huff_zero(s.d_status, 4 * (size_t)lay.n, up));
-  JB_HIP(ctx, jbk_huff_zero(d_out, zero_bytes, up));
+  JB_HIP(ctx, jbk_huff_zero(d_out, zero_bytes, up, s.d_status, 4 * (size_t)lay.n));  // (status words: 4 * 256 bytes are allocated)
   JbHuffLaunch p;
   memset(&p, 0, sizeof p);
   const uint8_t *d = (const uint8_t *)s.d_blob;

@@ -530,16 +530,21 @@ __global__ __launch_bounds__(256) void jb_huff_fetch_kernel(uint4 *dst, const ui
 }
 // the coefficient area and the status words are zeroed by a kernel of this library as well (the decoder stores
 // non-zero coefficients only)
-__global__ __launch_bounds__(256) void jb_huff_zero_kernel(uint4 *dst, uint64_t n16) {
+// (`small`: a second, small region -- the submission's status words, at most 256 of them -- zeroed by the first
+// workgroup of the same launch: a launch of its own cost 5 us per submission)
+__global__ __launch_bounds__(256) void jb_huff_zero_kernel(uint4 *dst, uint64_t n16, uint4 *small, uint32_t small16) {
   const uint4 z = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x < small16) small[threadIdx.x] = z;
   for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256u) dst[i] = z;
 }
-hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream) {
+hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream, void *d_small, size_t small_bytes) {
   (void)hipGetLastError();
   const uint64_t n16 = (bytes + 15) / 16;
   uint64_t blocks = (n16 + 255u) / 256u;
   if (blocks > 8192u) blocks = 8192u;
-  hipLaunchKernelGGL(jb_huff_zero_kernel, dim3((unsigned)(blocks ? blocks : 1u)), dim3(256), 0, stream, (uint4 *)d_dst, n16);
+  const uint32_t small16 = d_small ? (uint32_t)((small_bytes + 15) / 16) : 0u;
+  if (small16 > 256u) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(jb_huff_zero_kernel, dim3((unsigned)(blocks ? blocks : 1u)), dim3(256), 0, stream, (uint4 *)d_dst, n16, (uint4 *)d_small, small16);
   return hipGetLastError();
 }
 hipError_t jbk_huff_fetch(void *d_dst, const void *h_pinned_src, size_t bytes, hipStream_t stream) {

@@ -42,5 +42,6 @@ hipError_t jbk_huff_launch(const JbHuffLaunch &p, hipStream_t stream);
 // small pinned host blob -> device by a kernel (no copy-engine hand-over in front of the decoding kernels);
 // bytes is rounded up to 16: both buffers are allocated with that slack
 // zero `bytes` (rounded up to 16) of device memory by a kernel
-hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream);
+// (d_small / small_bytes: a second region of at most 4 KB, rounded up to 16 bytes, zeroed by the same launch)
+hipError_t jbk_huff_zero(void *d_dst, size_t bytes, hipStream_t stream, void *d_small = nullptr, size_t small_bytes = 0);
 hipError_t jbk_huff_fetch(void *d_dst, const void *h_pinned_src, size_t bytes, hipStream_t stream);

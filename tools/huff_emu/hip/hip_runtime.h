@@ -34,6 +34,7 @@ struct dim3 {
 typedef void *hipStream_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
+constexpr hipError_t hipErrorInvalidValue = 1;
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
 namespace emu {
