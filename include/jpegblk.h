@@ -52,6 +52,7 @@
  *   JPEGBLK_ROW_TILING     1 = the row-bound tiling for every image
  *   JPEGBLK_PASS1          1 = a batch run always reads every file's headers first (default: only while the decoder's
  *                          buffers do not exist yet; otherwise a file is parsed when its group is formed)
+ *   JPEGBLK_GROUP_RAMP     1 = a host thread's first two device groups are a quarter and a half of the full size
  *   JPEGBLK_GROUP_MB       MB of coefficients per group of small images on the host path (16; 0 = one image per submission)
  *   JPEGBLK_DEV_GROUP_MB   MB of coefficients per group whose entropy stage runs on the device (96)
  *   JPEGBLK_NUMA           0 = leave the host threads' CPU affinity alone, 1 = always bind them to the GPU's node

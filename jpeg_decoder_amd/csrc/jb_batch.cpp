@@ -509,10 +509,12 @@ void decode_pass(const Run &r, Lane *lane, int t, std::vector<Parsed> &parsed, i
     int room_dev = (int)(droom_c < droom_p ? droom_c : droom_p);
     if (room_dev > dev_max_group) room_dev = dev_max_group;
     const int room_dev_full = room_dev < 1 ? 1 : room_dev;
-    // The thread's first two device groups are a quarter and a half of the full size: the device and the link get
-    // their first work after two images' worth of host time instead of eight, which is what a batch whose share
-    // per thread is about one group (128 1080p files on 16 threads) otherwise waits for before anything overlaps.
-    if (dev_groups < 2) room_dev = room_dev >> (2 - dev_groups);
+    // (JPEGBLK_GROUP_RAMP=1: the thread's first two device groups a quarter and a half of the full size, so that the
+    // device gets its first work sooner.  It paid while every run began with a pass over all headers; since files
+    // are parsed as their groups are formed the first submission leaves after 1 ms anyway, and fewer, larger groups
+    // win: 1,024 1080p files left in HBM 33-35 k -> 41.6-42.1 k images/s, 128 files 21 k -> 26 k, 128 files to the
+    // arena 6,700 -> 7,240, interleaved on one box.  Off by default.)
+    if (dev_groups < 2 && r.knobs->group_ramp) room_dev = room_dev >> (2 - dev_groups);
     if (room_dev < 1) room_dev = 1;
     // entropy-decode consecutive images of the head's geometry into the slot, back to back -- or,
     // for files with restart intervals, only ready them for the device decoder

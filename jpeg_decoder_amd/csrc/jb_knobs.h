@@ -19,6 +19,7 @@
 //                         of up to 8 workgroups per CU of the 192-lane kernel, e.g. one to four 1080p images, one 4096x4096 4:2:0)
 //   JPEGBLK_PASS1         1: a batch run always reads every file's headers first (default: only a decoder whose
 //                         buffers do not exist yet does; otherwise files are parsed as their groups are formed)
+//   JPEGBLK_GROUP_RAMP    1: a thread's first two device groups are a quarter and a half of the full size (default: full)
 //   JPEGBLK_GROUP_MB      MB of coefficients per group of small images decoded on the host threads (default 16; 0: one image per submission)
 //   JPEGBLK_DEV_GROUP_MB  MB of coefficients per group whose entropy stage runs on the device (default 96)
 //   JPEGBLK_NUMA          0: leave the host threads' CPU affinity alone; 1: bind them to the GPU's NUMA node even
@@ -37,6 +38,7 @@ struct JbKnobs {
   bool byte_store = false;
   bool row_tiling = false;
   bool pass1 = false;
+  bool group_ramp = false;
   int small_grid = -1;       // -1: automatic
   int staged_store = 0;
   long group_mb = -1;        // -1: the default
@@ -61,6 +63,7 @@ inline JbKnobs jb_knobs_read() {
   k.byte_store = flag("JPEGBLK_BYTE_STORE");
   k.row_tiling = flag("JPEGBLK_ROW_TILING");
   k.pass1 = flag("JPEGBLK_PASS1");
+  k.group_ramp = flag("JPEGBLK_GROUP_RAMP");
   if (const char *e = getenv("JPEGBLK_STAGED_STORE")) k.staged_store = e[0] == '1' ? 1 : 0;
   if (const char *e = getenv("JPEGBLK_SMALL_GRID")) k.small_grid = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1;
   if (const char *e = getenv("JPEGBLK_GROUP_MB")) k.group_mb = atol(e) < 0 ? 0 : atol(e);
