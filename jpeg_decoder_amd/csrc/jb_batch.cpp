@@ -131,13 +131,14 @@ struct Parsed {
 };
 
 constexpr int kMaxSlots = 4;
-// pinned buffers per host thread = its submissions in flight: decode group k while k-1 .. k-n+1 are on the device.
-// Host output (pageable buffers or the pinned arena) is bound by the download, and there two slots do: three or
-// four, smaller groups, and first groups of different sizes per thread were measured on 1,024 1080p and 64
-// 8192x8192 files and stayed inside the run-to-run spread (profiles/r02b/ab_pipeline_depth.txt).  Device-resident
-// output is bound by the latency of a group's launches: there four slots and smaller groups are worth
-// +35 % (1,024 1080p files: 13,400 -> 18,400 images/s) and +25 % (8192x8192: 1,090 -> 1,420), same file.
-int lane_slots(bool device_output) { return device_output ? kMaxSlots : 2; }
+// pinned buffers per host thread = its submissions in flight: decode group k while k-1 is on the device.  Two, whatever
+// the output: with the host's entropy stage the second slot is what lets a thread decode while its last group uploads;
+// with the device's, 16 threads x 1 already keep the device and the link busy, and more than two changes nothing
+// (profiles/r03/ab_slots_per_thread.txt: 1 / 2 / 3 / 4 slots, 1,024 1080p files left in HBM 42.5-43.3 / 41.1-41.5 /
+// 41.1-41.9 / 40.4-40.6 k images/s, to the arena 8,250 / 8,180-8,260 / 8,150-8,170 / 8,160-8,200; 32 8192x8192 files
+// left in HBM 2,060-2,170 / 1,730-1,810 / 1,750-1,780 / 1,760-1,770).  (Round 2's kernels wanted four for
+// device-resident output -- +35 % -- because a group's launches took milliseconds: profiles/r02b/ab_pipeline_depth.txt.)
+int lane_slots(bool /*device_output*/) { return 2; }
 
 // what one host thread owns across runs: the pinned buffers its Huffman stage decodes into and,
 // when the caller's pixel buffers are pageable (no arena), pinned pixel staging -- a
