@@ -44,7 +44,7 @@
  * context (jb_ctx_create) or a batch decoder (jb_batch_decoder_create*, jb_decode_batch) is created
  * -- and kept there (csrc/jb_knobs.h is the one place that reads them):
  *   JPEGBLK_GPU_HUFFMAN    where the entropy stage runs: unset = batch decoders on the device for files
- *                          of 16 chunks (2 KB of scan) or more, single images from 256 KB of scan on;
+ *                          of 16 chunks (2 KB of scan) or more, single images from 128 KB of scan on;
  *                          0 = always the host threads (north_star's split); 1 = the device for every
  *                          file of 16 chunks or more; 2 = the device for every file it takes
  *   JPEGBLK_CHUNK_BYTES    64 | 128: scan bytes per lane of the device entropy decoder (default 128)
@@ -258,7 +258,7 @@ int jb_entropy_decode_mt(const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *
  * accepts (16 chunks = 2 KB of scan or more) and fall back to the host decoder per image for whatever it
  * does not take or flags; JPEGBLK_GPU_HUFFMAN=0 keeps the entropy stage on the host threads (north_star's
  * split), =2 drops the size threshold.  The single-image jb_decode_file / jb_decode_memory take it for files
- * with 256 KB of entropy-coded data or more, where one image's latency is lower on the device (1920x1080
+ * with 128 KB of entropy-coded data or more, where one image's latency is lower on the device (1920x1080
  * 4:4:4: 0.51 ms against 3.9 ms on one host core; 679x451: 0.75-0.95 against 0.7), with
  * JPEGBLK_GPU_HUFFMAN=1 or 2 for every file the device decoder takes, with =0 never. */
 int jb_entropy_decode_device(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, jb_image_desc *desc,

@@ -439,15 +439,15 @@ int jb_decode_memory(jb_ctx *ctx, const uint8_t *jpeg, size_t jpeg_bytes, uint8_
   // parses the headers and removes the byte stuffing.  One image is one latency-bound submission
   // (a dozen and a half launches: about 1 ms whatever the size, then ~0.4 ms per megabyte of scan)
   // against 5.5 ms per megabyte on one host core, so by default the device takes files of
-  // kAutoDeviceScan bytes of scan or more -- measured: 679x451 (80 KB) 1.1-1.4 ms against 0.7 on the
-  // host, 1024x768 4:2:0 (204 KB) 1.37 against 1.21, 1280x720 4:2:0 (238 KB) 1.19 against 1.37,
-  // 1920x1080 4:4:4 (760 KB) 0.84 against 3.9, 8192x8192 4:2:0 (17 MB) 8.2 against 92
-  // (tools/single_latency.py).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
+  // kAutoDeviceScan bytes of scan or more -- measured with round 3's kernels: 679x451 (80 KB) 0.56-0.85 ms against
+  // 0.67-0.73 on the host, 1024x768 4:2:0 (204 KB) 0.63 against 1.19, 1280x720 4:2:0 (238 KB) 0.57 against 1.36,
+  // 1920x1080 4:4:4 (760 KB) 0.51 against 3.9, 8192x8192 4:2:0 (17 MB) 7.5 against 94
+  // (tools/single_latency.py, profiles/r03/single_latency.txt; the threshold was 256 KB with round 2's kernels).  JPEGBLK_GPU_HUFFMAN=0: always the host decoder;
   // =1: the device for every file with 16 restart intervals / chunks or more; =2: also fewer intervals.
   // Whatever the device decoder does not take or flags as corrupt goes through the host decoder
   // below, which gives the precise answer.
   {
-    constexpr size_t kAutoDeviceScan = (size_t)256 << 10;
+    constexpr size_t kAutoDeviceScan = (size_t)128 << 10;
     const JbKnobs &knobs = *jb_ctx_knobs_(ctx);  // (read when the context was created: jb_knobs.h)
     const bool forced = knobs.gpu_huffman == 1 || knobs.gpu_huffman == 2;
     const bool automatic = knobs.gpu_huffman < 0;

@@ -6,7 +6,7 @@
 // select a path for tests and A/B measurements, or adapt the host side to its machine.
 //
 //   JPEGBLK_GPU_HUFFMAN   where the entropy stage runs.  unset: batch decoders on the device for every file with
-//                         16 chunks or more, single images (decode(path)) from 256 KB of scan on; 0: always on the
+//                         16 chunks or more, single images (decode(path)) from 128 KB of scan on; 0: always on the
 //                         host threads (north_star's split); 1: the device for every file with 16 chunks or more;
 //                         2: the device for every file it takes
 //   JPEGBLK_CHUNK_BYTES   64 | 128: bytes of scan per lane of the device entropy decoder (default 128)
